@@ -1,0 +1,251 @@
+"""Golden-vector generator -- runs the REFERENCE (imported via oracle/ref_harness.py)
+on seeded synthetic inputs and writes its outputs under tests/golden/.
+
+Run in the build container only (needs /root/reference):
+    python -m oracle.gen_golden
+
+Inputs are not stored: they are regenerated from seeds by ``trace_amd.synthetic`` and
+``trace_amd.weights.random_state_dict`` (CPU torch generators, bitwise reproducible
+for this image's torch build); the fixtures hold the recipe (seeds/shape) plus the
+reference's outputs.  The reference's own tests hold no vectors for this path
+(SURVEY.md section 4), so these files are what pins parity.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle import ref_harness as rh                          # noqa: E402
+from trace_amd import synthetic as syn                        # noqa: E402
+from trace_amd.config import ModelConfig                      # noqa: E402
+from trace_amd.weights import random_state_dict               # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# ---- shared case definitions (imported by the tests, which rebuild the inputs) ---- #
+def case_inputs(name):
+    """Returns dict(cfg, sd_seed, batch, guidance, kwargs, noise) for a named case."""
+    cfg = ModelConfig()
+    aps = [3, 2]
+    N = 2
+    spec = {
+        "unguided_w0": dict(dense=False, w=0.0, guide=None, clean=False, apply=True),
+        "cfg_w05": dict(dense=False, w=0.5, guide=None, clean=False, apply=True),
+        "clean_all": dict(dense=True, w=0.5, guide="all", clean=True, apply=True),
+        "noisy_all": dict(dense=True, w=0.0, guide="all", clean=False, apply=True),
+        "filter_only": dict(dense=True, w=0.0, guide="all", clean=False, apply=False),
+        "clean_misc": dict(dense=False, w=0.0, guide="misc", clean=True, apply=True),
+    }[name]
+    batch = syn.make_batch(cfg, aps, seed=1, extent=(0.9, 0.7, 1.75), dense=spec["dense"])
+    guide = None
+    if spec["guide"] == "all":
+        guide = syn.merge_guidance(
+            syn.target_pos_guidance(batch, aps, weight=30000.0, seed=5),
+            syn.collision_guidance(aps, agent_weight=1000.0, map_weight=10.0, num_disks=2))
+    elif spec["guide"] == "misc":
+        wfa = batch["world_from_agent"]
+        far = (wfa[:3, :2, :2] @ torch.tensor([30.0, 4.0]) + wfa[:3, :2, 2]).tolist()
+        near = (wfa[3:, :2, :2] @ torch.tensor([3.0, -1.0]) + wfa[3:, :2, 2]).tolist()
+        guide = [
+            [{"name": "global_target_pos", "weight": 10000.0,
+              "params": {"target_pos": far, "urgency": [0.7, 0.2, 1.0], "pref_speed": 1.25,
+                         "dt": 0.1, "min_progress_dist": 0.5}, "agents": None},
+             {"name": "target_speed", "weight": 50.0,
+              "params": {"target_speed": 1.5, "dt": 0.1}, "agents": [0, 2]},
+             {"name": "min_speed", "weight": 20.0, "params": {"min_speed": 2.5, "dt": 0.1},
+              "agents": [1]}],
+            [{"name": "global_target_pos", "weight": 10000.0,
+              "params": {"target_pos": near, "urgency": [0.5, 0.9], "pref_speed": 1.25,
+                         "dt": 0.1, "min_progress_dist": 0.5}, "agents": None},
+             {"name": "target_pos_at_time", "weight": 300.0,
+              "params": {"target_pos": [[2.0, 0.5]], "target_time": [30]}, "agents": [1]},
+             {"name": "global_target_pos_at_time", "weight": 200.0,
+              "params": {"target_pos": [near[0], far[0]], "target_time": [40, 200],
+                         "urgency": [0.5, 0.8], "pref_speed": 1.25, "dt": 0.1}, "agents": None}],
+        ]
+    init, steps = syn.make_noise(cfg, sum(aps), N, seed=3)
+    return dict(cfg=cfg, sd_seed=0, aps=aps, num_samp=N, batch=batch, guidance=guide,
+                w=spec["w"], clean=spec["clean"], apply=spec["apply"],
+                noise_init=init, noise_steps=steps, step_index=7)
+
+
+CASES = ["unguided_w0", "cfg_w05", "clean_all", "noisy_all", "filter_only", "clean_misc"]
+FULL_DIFFUSION = {"unguided_w0", "clean_all", "noisy_all", "clean_misc"}
+
+
+def _quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def run_case(name, ref_cache={}):
+    ns = rh.load_reference()
+    c = case_inputs(name)
+    cfg, batch = c["cfg"], c["batch"]
+    sd = random_state_dict(cfg, c["sd_seed"])
+    with _quiet():
+        model = rh.build_reference_model(cfg.to_algo_dict(), sd, batch["map_grid_feat"],
+                                         batch["map_grid_feat_non_cond"])
+        if c["guidance"] is not None:
+            model.set_guidance(c["guidance"], batch)
+            model.update_guidance(global_t=c["step_index"])
+    tape = [c["noise_init"]] + [c["noise_steps"][i] for i in range(cfg.n_diffusion_steps)]
+    with rh.noise_tape(tape), _quiet():
+        out = model(batch, num_samp=c["num_samp"], return_diffusion=True,
+                    return_guidance_losses=True, class_free_guide_w=c["w"],
+                    apply_guidance=c["apply"], guide_clean=c["clean"])
+    pred = out["predictions"]
+    res = {"positions": pred["positions"].numpy(), "yaws": pred["yaws"].numpy()}
+    d = pred["diffusion_steps"]
+    if name in FULL_DIFFUSION:
+        res["diffusion_steps"] = d.numpy()
+    else:
+        res["diffusion_steps_last"] = d[:, :, :, -1].numpy()
+    if pred.get("guide_losses") is not None:
+        for k, v in pred["guide_losses"].items():
+            res["guide_loss/" + k] = v.numpy()
+        B = pred["positions"].shape[0]
+        idx = ns.guidance.choose_action_from_guidance(
+            pred, batch, model.current_guidance.guide_configs, pred["guide_losses"])
+        res["act_idx"] = idx.numpy()
+    return res
+
+
+def run_components():
+    """Per-component vectors from the reference's own functions."""
+    ns = rh.load_reference()
+    cfg = ModelConfig()
+    res = {}
+    sd = random_state_dict(cfg, 0)
+    aps = [3, 2]
+    batch = syn.make_batch(cfg, aps, seed=1, extent=(0.9, 0.7, 1.75), dense=True)
+    with _quiet():
+        model = rh.build_reference_model(cfg.to_algo_dict(), sd, batch["map_grid_feat"],
+                                         batch["map_grid_feat_non_cond"])
+    # schedule tables
+    for k in ["betas", "alphas_cumprod", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+              "posterior_variance", "posterior_log_variance_clipped", "posterior_mean_coef1",
+              "posterior_mean_coef2", "sqrt_alphas_over_one_minus_alphas_cumprod",
+              "sqrt_recip_one_minus_alphas_cumprod"]:
+        res["tab/" + k] = getattr(model, k).numpy()
+    # conditioning
+    aux = model.get_aux_info(batch, True)
+    res["aux/cond_feat"] = aux["cond_feat"].numpy()
+    res["aux/non_cond_feat"] = aux["non_cond_feat"].numpy()
+    # dynamics forward + gradient (large actions so every clip is exercised)
+    g = torch.Generator().manual_seed(11)
+    B = sum(aps)
+    act = (torch.randn(B, cfg.horizon, 2, generator=g) * torch.tensor([6.0, 3.0])).requires_grad_()
+    init = aux["curr_states"].clone()
+    init[:, 2] *= torch.tensor([1.0, 30.0, -11.0, 12.0, 0.02])
+    st = ns.helpers.unicyle_forward_dynamics(model.dyn, init, act, cfg.step_time, mode="parallel")
+    wgt = torch.randn(st.shape, generator=g)
+    gr, = torch.autograd.grad((st * wgt).sum(), act)
+    res["dyn/states"] = st.detach().numpy()
+    res["dyn/grad"] = gr.numpy()
+    # map query + UNet forward / input VJP
+    x = torch.randn(B, cfg.horizon, 6, generator=g)
+    feats = model.query_map_feats(x, aux["map_grid_feat"], aux["raster_from_agent"])
+    res["mapq/feats"] = feats.numpy()
+    xin = torch.cat([x, feats], dim=-1).requires_grad_()
+    t = torch.tensor([99, 50, 0, 7, 63])
+    with _quiet():
+        y = model.model(xin, aux["cond_feat"], t)
+    wy = torch.randn(y.shape, generator=g)
+    gx, = torch.autograd.grad((y * wy).sum(), xin)
+    res["unet/out"] = y.detach().numpy()
+    res["unet/grad_in"] = gx.numpy()
+    # every guidance objective: value + gradient w.r.t. the (descaled) trajectory
+    N = 3
+    a = torch.randn(B * N, cfg.horizon, 2, generator=g) * torch.tensor([1.0, 0.6])
+    cs = aux["curr_states"].repeat_interleave(N, 0)
+    xs = ns.helpers.unicyle_forward_dynamics(model.dyn, cs, a, cfg.step_time, mode="parallel")
+    traj = torch.cat([xs, a], dim=-1).reshape(B, N, cfg.horizon, 6)
+    res["loss/traj"] = traj.numpy()
+    for lname, cfgs in loss_component_configs(batch, aps).items():
+        tr = traj.clone().requires_grad_()
+        guid = ns.guidance.DiffuserGuidance(cfgs, batch)
+        guid.update(global_t=7)
+        tot, per = guid.compute_guidance_loss(tr, batch)
+        gt, = torch.autograd.grad(tot, tr)
+        res["loss/%s/total" % lname] = tot.detach().numpy()
+        res["loss/%s/grad" % lname] = gt.numpy()
+        for k, v in per.items():
+            res["loss/%s/per/%s" % (lname, k)] = v.numpy()
+    return res
+
+
+def loss_component_configs(batch, aps):
+    """One guidance config list per objective (shared with the tests)."""
+    wfa = batch["world_from_agent"]
+    far = (wfa[:3, :2, :2] @ torch.tensor([30.0, 4.0]) + wfa[:3, :2, 2]).tolist()
+    near = (wfa[3:, :2, :2] @ torch.tensor([3.0, -1.0]) + wfa[3:, :2, 2]).tolist()
+    none2 = lambda c: [c, []]
+    return {
+        "target_pos": syn.target_pos_guidance(batch, aps, weight=3.0, seed=5),
+        "target_pos_min_t": [[{"name": "target_pos", "weight": 2.0,
+                               "params": {"target_pos": [[3.0, 0.5], [2.0, -1.0]],
+                                          "min_target_time": 0.5}, "agents": [0, 2]}], []],
+        "agent_collision_d1": [
+            [{"name": "agent_collision", "weight": 1.5,
+              "params": {"num_disks": 1, "buffer_dist": 0.2}, "agents": None}],
+            [{"name": "agent_collision", "weight": 0.5,
+              "params": {"num_disks": 1, "buffer_dist": 0.2}, "agents": None}]],
+        "agent_collision_d5_sub": [
+            [{"name": "agent_collision", "weight": 2.0,
+              "params": {"num_disks": 5, "buffer_dist": 0.3}, "agents": [0, 1]}], []],
+        "map_collision": [
+            [{"name": "map_collision", "weight": 1.0, "params": {"num_points_lw": [10, 10]},
+              "agents": None}],
+            [{"name": "map_collision", "weight": 2.0, "params": {"num_points_lw": [10, 10]},
+              "agents": [1]}]],
+        "target_pos_at_time": [[], [{"name": "target_pos_at_time", "weight": 4.0,
+                                     "params": {"target_pos": [[2.0, 0.5], [1.0, 1.0]],
+                                                "target_time": [30, 51]}, "agents": None}]],
+        "global_target_pos": [
+            [{"name": "global_target_pos", "weight": 5.0,
+              "params": {"target_pos": far, "urgency": [0.7, 0.01, 1.0], "pref_speed": 1.25,
+                         "dt": 0.1, "min_progress_dist": 0.5}, "agents": None}],
+            [{"name": "global_target_pos", "weight": 5.0,
+              "params": {"target_pos": near, "urgency": [0.5, 0.9], "pref_speed": 1.25,
+                         "dt": 0.1, "min_progress_dist": 0.5}, "agents": None}]],
+        "global_target_pos_at_time": [[], [{"name": "global_target_pos_at_time", "weight": 2.0,
+                                            "params": {"target_pos": [near[0], far[0]],
+                                                       "target_time": [40, 200],
+                                                       "urgency": [0.5, 0.8], "pref_speed": 1.25,
+                                                       "dt": 0.1}, "agents": None}]],
+        "target_speed": none2([{"name": "target_speed", "weight": 3.0,
+                                "params": {"target_speed": 1.5, "dt": 0.1},
+                                "agents": [0, 2]}]),
+        "target_speed_pos": none2([{"name": "target_speed", "weight": 3.0,
+                                    "params": {"target_speed": 1.2, "dt": 0.1,
+                                               "mode": "use_position"}, "agents": None}]),
+        "min_speed": none2([{"name": "min_speed", "weight": 2.0,
+                             "params": {"min_speed": 2.5, "dt": 0.1}, "agents": [1]}]),
+    }
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    comp = run_components()
+    np.savez_compressed(os.path.join(OUT, "components.npz"), **comp)
+    print("components:", len(comp), "arrays")
+    for name in CASES:
+        res = run_case(name)
+        np.savez_compressed(os.path.join(OUT, "sample_%s.npz" % name), **res)
+        print(name, {k: v.shape for k, v in res.items() if not k.startswith("guide_loss")})
+    meta = {"torch": torch.__version__, "numpy": np.__version__,
+            "generator": "oracle/gen_golden.py", "cases": CASES}
+    with open(os.path.join(OUT, "META.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+"""Pins the CPU oracle (oracle/trace_oracle.py) against golden vectors emitted by the
+reference itself (oracle/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trace_oracle as orc
+from oracle.gen_golden import CASES, FULL_DIFFUSION, case_inputs, loss_component_configs
+from trace_amd import synthetic as syn
+from trace_amd.config import ModelConfig
+from trace_amd.weights import random_state_dict
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    return dict(np.load(os.path.join(GOLDEN, name)))
+
+
+def _close(a, b, rtol=1e-5, atol=1e-6):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
+
+
+@pytest.fixture(scope="module")
+def comp():
+    return _load("components.npz")
+
+
+@pytest.fixture(scope="module")
+def setup():
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 0)
+    aps = [3, 2]
+    batch = syn.make_batch(cfg, aps, seed=1, extent=(0.9, 0.7, 1.75), dense=True)
+    return cfg, sd, aps, batch
+
+
+def test_schedule_tables_bit_exact(comp):
+    tab = orc.schedule_tables(100)
+    for k, v in tab.items():
+        assert np.array_equal(comp["tab/" + k], v.numpy()), k
+
+
+def test_conditioning(comp, setup):
+    cfg, sd, aps, batch = setup
+    aux = orc.get_aux_info(sd, cfg, batch, True)
+    _close(aux["cond_feat"], comp["aux/cond_feat"], 0, 0)
+    _close(aux["non_cond_feat"], comp["aux/non_cond_feat"], 0, 0)
+
+
+def test_dynamics_forward_and_grad(comp, setup):
+    cfg, sd, aps, batch = setup
+    g = torch.Generator().manual_seed(11)
+    B = sum(aps)
+    act = (torch.randn(B, cfg.horizon, 2, generator=g) * torch.tensor([6.0, 3.0])).requires_grad_()
+    init = torch.zeros(B, 4)
+    init[:, 2] = batch["curr_speed"] * torch.tensor([1.0, 30.0, -11.0, 12.0, 0.02])
+    st = orc.unicycle_rollout(cfg, init, act)
+    wgt = torch.randn(st.shape, generator=g)
+    gr, = torch.autograd.grad((st * wgt).sum(), act)
+    _close(st.detach(), comp["dyn/states"], 1e-6, 1e-6)
+    _close(gr, comp["dyn/grad"], 1e-6, 1e-6)
+    # the fixture must exercise every clip
+    a = act.detach()
+    assert (a[..., 0] > cfg.acce_bound[1]).any() and (a[..., 0] < cfg.acce_bound[0]).any()
+    assert (st[..., 2] >= cfg.vbound[1]).any() and (st[..., 2] <= cfg.vbound[0]).any()
+    assert (gr[..., 1] == 0).any() and (gr[..., 1] != 0).any()
+
+
+def test_map_query_and_unet(comp, setup):
+    cfg, sd, aps, batch = setup
+    g = torch.Generator().manual_seed(11)
+    B = sum(aps)
+    torch.randn(B, cfg.horizon, 2, generator=g)
+    torch.randn(B, cfg.horizon, 4, generator=g)
+    x = torch.randn(B, cfg.horizon, 6, generator=g)
+    aux = orc.get_aux_info(sd, cfg, batch, True)
+    feats = orc.query_map_feats(cfg, x, aux["map_grid_feat"], aux["raster_from_agent"])
+    _close(feats, comp["mapq/feats"], 0, 0)
+    xin = torch.cat([x, feats], dim=-1).requires_grad_()
+    t = torch.tensor([99, 50, 0, 7, 63])
+    y = orc.unet_forward(sd, cfg, xin, aux["cond_feat"], t)
+    wy = torch.randn(y.shape, generator=g)
+    gx, = torch.autograd.grad((y * wy).sum(), xin)
+    _close(y.detach(), comp["unet/out"], 1e-6, 1e-6)
+    _close(gx, comp["unet/grad_in"], 1e-5, 1e-6)
+
+
+def test_guidance_objectives(comp, setup):
+    cfg, sd, aps, batch = setup
+    traj0 = torch.tensor(comp["loss/traj"])
+    active = {}
+    for lname, cfgs in loss_component_configs(batch, aps).items():
+        tr = traj0.clone().requires_grad_()
+        guid = orc.Guidance(cfgs)
+        guid.update(global_t=7)
+        tot, per = guid.loss(tr, batch)
+        gt, = torch.autograd.grad(tot, tr)
+        _close(tot.detach(), comp["loss/%s/total" % lname], 1e-6, 1e-7)
+        _close(gt, comp["loss/%s/grad" % lname], 1e-5, 1e-7)
+        for k, v in per.items():
+            _close(v, comp["loss/%s/per/%s" % (lname, k)], 1e-6, 1e-7)
+        active[lname] = float(gt.abs().max())
+    # every objective must be active in the fixture (non-trivial gradient)
+    for k, v in active.items():
+        assert v > 0, k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_sampler_end_to_end(name):
+    c = case_inputs(name)
+    gold = _load("sample_%s.npz" % name)
+    o = orc.OracleSampler(c["cfg"], random_state_dict(c["cfg"], c["sd_seed"]))
+    o.set_guidance(c["guidance"])
+    res = o.get_action(c["batch"], c["num_samp"], c["w"], guide_as_filter_only=not c["apply"],
+                       guide_clean=c["clean"], step_index=c["step_index"],
+                       noise_init=c["noise_init"], noise_steps=c["noise_steps"])
+    s = res["samples"]
+    if name in FULL_DIFFUSION:
+        _close(s["diffusion_steps"], gold["diffusion_steps"], 2e-5, 2e-5)
+    else:
+        _close(s["diffusion_steps"][:, :, :, -1], gold["diffusion_steps_last"], 2e-5, 2e-5)
+    _close(s["positions"], gold["positions"], 2e-5, 2e-5)
+    _close(s["yaws"], gold["yaws"], 2e-5, 2e-5)
+    if c["guidance"] is not None:
+        for k, v in s["guide_losses"].items():
+            _close(v, gold["guide_loss/" + k], 1e-4, 1e-6)
+        assert np.array_equal(res["act_idx"].numpy(), gold["act_idx"])
