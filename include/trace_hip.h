@@ -1,0 +1,231 @@
+/*
+ * trace_hip.h -- C ABI of libtrace_hip.so: the MI355X (gfx950) kernels of the TRACE guided
+ * trajectory-diffusion sampler.
+ *
+ * The reference (nv-tlabs/trace) has no FFI: its hot path is Python calling ATen.  Each entry
+ * point below replaces the ATen op group of one reference function (cited as
+ * tbsim/...:line, relative to the reference root) and is what a binding for this path would
+ * bind (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless named *_host
+ *   - all tensors fp32, row-major, contiguous unless a stride argument says otherwise
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only enqueue
+ *   - no hidden device allocation after trace_unet_create(): scratch comes in as `workspace`
+ *   - return 0 on success, negative TRACE_E* otherwise; trace_last_error() holds the text
+ *   - M = trajectories (agents x samples), trajectory index m = agent * num_samp + sample
+ *     (tbsim/utils/tensor_utils.py:664-677), T = horizon, state layout (x,y,v,yaw,acc,yawvel)
+ */
+#ifndef TRACE_HIP_H
+#define TRACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRACE_OK 0
+#define TRACE_EINVAL (-1)   /* bad argument / unsupported shape */
+#define TRACE_EHIP (-2)     /* a HIP runtime call failed */
+#define TRACE_ENOMEM (-3)   /* workspace too small */
+
+const char* trace_last_error(void);
+int trace_abi_version(void);
+
+/* ------------------------------------------------------------------ denoiser ---- */
+/* Temporal UNet hyper-parameters (tbsim/models/temporal.py:49-115). */
+typedef struct {
+  int horizon;        /* 52 */
+  int in_channels;    /* 6 + map_grid_feature_dim = 38 */
+  int n_levels;       /* 3 */
+  int dims[4];        /* channels per level: 64,128,256 (first n_levels entries used) */
+  int cond_dim;       /* 256 */
+  int time_dim;       /* 32 */
+  int n_groups;       /* 8 */
+  int n_steps;        /* diffusion steps: 100 */
+} trace_unet_config;
+
+typedef struct trace_unet trace_unet;
+
+/* Number of fp32 parameters trace_unet_create expects, for `cfg`. */
+int64_t trace_unet_param_count(const trace_unet_config* cfg);
+
+/* Builds the denoiser from a flat HOST array of parameters in canonical order
+ * (documented in trace_amd/unet_params.py: residual blocks in execution order, then
+ * down/up-sample convs, final block, 1x1 head, time MLP).  Packs the weights into
+ * MFMA-fragment order for the forward and the input-VJP and uploads them.
+ * Replaces TemporalMapUnet.__init__ + load_state_dict (tbsim/models/temporal.py:51-115). */
+int trace_unet_create(const trace_unet_config* cfg, const float* params_host, int64_t n_params,
+                      trace_unet** out);
+void trace_unet_destroy(trace_unet* u);
+
+/* Floats per conditioning row in the table written by trace_unet_cond_table
+ * (sum of C_out over the residual blocks). */
+int trace_unet_cond_width(const trace_unet* u);
+
+/* table[r, :] = W_c * mish(cond[r, :]) + b for the per-block Linear layers' cond part
+ * (the `cond` columns of time_mlp.1 in ResidualTemporalMapBlockConcat,
+ * tbsim/models/temporal.py:22-26,44; the time columns are pre-tabulated per step at create
+ * time since t is shared by all rows).  cond: (n_rows, cond_dim). */
+int trace_unet_cond_table(const trace_unet* u, const float* cond, int n_rows, float* table,
+                          void* stream);
+
+/* Workspace bytes for `rows` denoiser rows; `save` != 0 keeps what the input-VJP needs. */
+int64_t trace_unet_workspace_bytes(const trace_unet* u, int rows, int save);
+
+/* One denoiser evaluation, TemporalMapUnet.forward (tbsim/models/temporal.py:117-142).
+ *   x_in   (rows, in_channels padded to 48, horizon)  channel-major, as written by
+ *          trace_map_query; pad channels must be zero
+ *   cond_table (n_cond_rows, cond_width); row r uses table row r / rows_per_cond
+ *   step   diffusion step t (same for all rows, tbsim/models/trace.py:738)
+ *   pred   (rows, horizon, 2)
+ * With classifier-free guidance the caller stacks conditional and unconditional rows
+ * (rows = 2M) so both passes of tbsim/models/trace.py:572,588 run as one call. */
+int trace_unet_forward(trace_unet* u, const float* x_in, const float* cond_table,
+                       int rows_per_cond, int step, int rows, float* pred, void* workspace,
+                       int64_t workspace_bytes, int save, void* stream);
+
+/* Input-VJP of the last trace_unet_forward(save=1) on the same workspace: the autograd
+ * backward the reference runs for clean guidance (tbsim/models/trace.py:630,640-649),
+ * restricted to the trajectory channels the sampler uses (:674-676).
+ *   grad_pred (rows, horizon, 2)
+ *   grad_x    (rows, horizon, 2): gradient w.r.t. input channels [4,5] (acc, yawvel). */
+int trace_unet_backward_input(trace_unet* u, const float* grad_pred, int rows, float* grad_x,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------- sampler steps ---- */
+/* Constants of the sampler: normalisation (tbsim/models/trace.py:415-447), unicycle bounds
+ * (tbsim/dynamics/unicycle.py:7-18), dt. */
+typedef struct {
+  float norm_add[6];
+  float norm_div[6];
+  float dt;
+  float acc_lo, acc_hi;   /* acce_bound */
+  float v_lo, v_hi;       /* vbound */
+  float max_steer;
+  float max_yawvel;
+} trace_dyn_params;
+
+/* Per-step scalars looked up from the schedule tables (tbsim/models/trace.py:170-203). */
+typedef struct {
+  float sqrt_recip_alphas_cumprod;
+  float sqrt_recipm1_alphas_cumprod;
+  float posterior_mean_coef1;
+  float posterior_mean_coef2;
+  float posterior_log_variance_clipped;
+  float sqrt_alphas_over_one_minus_alphas_cumprod;
+  float sqrt_recip_one_minus_alphas_cumprod;
+  int t;                  /* diffusion step; t == 0 disables noise and guidance */
+} trace_step_coefs;
+
+/* query_map_feats + concat + transpose (tbsim/models/trace.py:341-368,570;
+ * tbsim/models/trace_helpers.py:270-319; tbsim/utils/geometry_utils.py:105-171).
+ *   x (M, T, 6) scaled;  grid (n_agents, Hg, Wg, C) CHANNELS-LAST (the reference permutes to
+ *   this layout at trace_helpers.py:293 on every call; here the caller does it once per sampling
+ *   call), trajectory m reads grid m / num_samp (no per-sample copy, cf. trace.py:724);
+ *   raster_from_agent (n_agents, 3, 3);  x_in (M, c_pad, T): channels 0..5 = x, 6..6+C-1 =
+ *   bilinear map features; channels beyond are left untouched (must be zero). */
+int trace_map_query(const float* x, const float* grid, const float* raster_from_agent,
+                    float* x_in, int M, int num_samp, int T, int C, int Hg, int Wg, int c_pad,
+                    float img_w, float img_h, const trace_dyn_params* p, void* stream);
+
+/* Unicycle action->state rollout, mode='parallel'
+ * (tbsim/models/trace_helpers.py:387-475; wrapper tbsim/models/trace.py:390-413).
+ *   actions (M, T, 2), scaled_input != 0: descale channels [4,5] first
+ *   curr_states (n_agents, 4), trajectory m uses row m / num_samp
+ *   out (M, T, 6) = [states, descaled actions]; scaled_output != 0: scale all 6 channels. */
+int trace_dyn_rollout(const float* actions, const float* curr_states, float* out, int M,
+                      int num_samp, int T, int scaled_input, int scaled_output,
+                      const trace_dyn_params* p, void* stream);
+
+/* Adjoint of trace_dyn_rollout(scaled_input=1, scaled_output=0): given the gradient w.r.t. the
+ * descaled (M,T,6) trajectory returns the gradient w.r.t. the scaled actions (M,T,2)
+ * (autograd through tbsim/models/trace_helpers.py:431-475 and trace.py:399). */
+int trace_dyn_adjoint(const float* actions, const float* curr_states, const float* grad_traj,
+                      float* grad_actions, int M, int num_samp, int T, const trace_dyn_params* p,
+                      void* stream);
+
+/* Classifier-free-guidance combine, op-for-op as tbsim/models/trace.py:591-598 (no FMA
+ * contraction).  pred_c, pred_u (M,T,2); x (M,T,6); x0 (M,T,2).
+ * w == 0: x0 = pred_c (pred_u may be NULL). */
+int trace_cfg_combine(const float* pred_c, const float* pred_u, const float* x, float* x0, int M,
+                      int T, float w, const trace_step_coefs* c, void* stream);
+
+/* Scales the guidance gradient w.r.t. x0 into gradients w.r.t. the two denoiser outputs
+ * (chain rule through tbsim/models/trace.py:591-596 with x_t detached). */
+int trace_cfg_combine_adjoint(const float* grad_x0, float* grad_pred_c, float* grad_pred_u, int M,
+                              int T, float w, const trace_step_coefs* c, void* stream);
+
+/* q_posterior mean (tbsim/models/trace.py:552-559): mean = c1*x0 + c2*x[...,4:6]. */
+int trace_posterior_mean(const float* x0, const float* x, float* mean, int M, int T,
+                         const trace_step_coefs* c, void* stream);
+
+/* End of p_sample (tbsim/models/trace.py:653-704): applies guidance + noise and rolls the
+ * dynamics out again.  clean != 0: x0' = x0 - nz*grad; mean = c1*x0' + c2*x_t; a = mean + nz*sigma*noise
+ * (:683-693); else a = (c1*x0 + c2*x_t) - nz*grad + nz*sigma*noise (:695).  grad may be NULL.
+ * a_out (M,T,2) (optional) receives the scaled actions before the rollout; x_next (M,T,6). */
+int trace_posterior_step(const float* x0, const float* grad, const float* x, const float* noise,
+                         const float* curr_states, float* x_next, float* a_out, int M,
+                         int num_samp, int T, int clean, const trace_step_coefs* c,
+                         const trace_dyn_params* p, void* stream);
+
+/* ------------------------------------------------------ guidance objectives ---- */
+/* All objectives read the descaled trajectory traj (M,T,6), ADD their weighted gradient into
+ * grad_traj (M,T,6) (may be NULL: value only) and write the unweighted per-trajectory loss
+ * into loss (M) for trajectories of active agents (others untouched).  Per-agent tables have
+ * n_agents rows; `scale[a]` = weight / (|mask| * num_samp) is the factor of
+ * DiffuserGuidance.compute_guidance_loss (tbsim/utils/guidance_loss.py:919), 0 = inactive. */
+
+/* TargetPosLoss (guidance_loss.py:523-540): target (n_agents,2), t_min (n_agents) first step. */
+int trace_guide_target_pos(const float* traj, float* grad_traj, float* loss, const float* target,
+                           const int* t_min, const float* scale, int M, int num_samp, int T,
+                           void* stream);
+
+/* TargetPosAtTimeLoss (guidance_loss.py:488-501): target (n_agents,2), t_at (n_agents). */
+int trace_guide_target_pos_at_time(const float* traj, float* grad_traj, float* loss,
+                                   const float* target, const int* t_at, const float* scale,
+                                   int M, int num_samp, int T, void* stream);
+
+/* compute_progress_loss (guidance_loss.py:542-590) used by the Global* objectives.
+ * goal (n_agents): goal distance; mode[a] = 0: relu(final_dist - goal) (:573),
+ * 1: relu(goal - (init_dist - final_dist)) (:585-588). */
+int trace_guide_progress(const float* traj, float* grad_traj, float* loss, const float* target,
+                         const float* goal, const int* mode, const float* scale, int M,
+                         int num_samp, int T, void* stream);
+
+/* TargetSpeedLoss / MinSpeedLoss (guidance_loss.py:148-196).  kind 0: mean_t (v - s)^2 on the
+ * speed channel; 1: same on finite-difference speed; 2: mean_t gelu(s - fd speed)^2. */
+int trace_guide_speed(const float* traj, float* grad_traj, float* loss, const float* speed,
+                      const float* scale, int kind, float dt, int M, int num_samp, int T,
+                      void* stream);
+
+/* AgentCollisionLoss (guidance_loss.py:264-338) + transform_agents_to_world
+ * (tbsim/models/trace_helpers.py:343-364): all pairs inside each scene.
+ *   world_from_agent (n_agents,3,3); radius (n_agents); disk_x (n_agents, num_disks);
+ *   scene_start (n_agents): first agent of the agent's scene, scene_size (n_agents);
+ *   in_mask (n_agents): 1 if the agent is guided (rows kept, gradient allowed);
+ *   workspace: M*T*4 floats (world poses). */
+int trace_guide_agent_collision(const float* traj, float* grad_traj, float* loss,
+                                const float* world_from_agent, const float* radius,
+                                const float* disk_x, int num_disks, float buffer_dist,
+                                const int* scene_start, const int* scene_size,
+                                const int* in_mask, const float* scale, int n_agents,
+                                int num_samp, int T, float* workspace, void* stream);
+
+/* MapCollisionLoss (guidance_loss.py:382-464; tbsim/utils/metrics.py:216-240).
+ *   drivable (n_agents, H, W) uint8 (bool); extent (n_agents,3); raster_from_agent (n_agents,3,3)
+ *   local_pts (n_pts, 2): unit-box sample grid, cartesian_prod(linspace(-.5,.5,n_l),
+ *   linspace(-.5,.5,n_w)) as built at guidance_loss.py:356-358; n_pts <= 128
+ *   workspace: M*T floats (per-step losses). */
+int trace_guide_map_collision(const float* traj, float* grad_traj, float* loss,
+                              const uint8_t* drivable, const float* extent,
+                              const float* raster_from_agent, const float* local_pts, int n_pts,
+                              const float* scale, int H, int W, int M, int num_samp, int T,
+                              float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRACE_HIP_H */

@@ -1,0 +1,283 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the golden
+vectors emitted by the reference.  Run on the MI355X box with ``-m gpu``.
+
+Tolerances (BASELINE.json north_star): fp32, 1e-4 relative per teacher-forced step,
+1e-3 m final ADE free-running.  "relative" is taken as |a-b| <= tol * (1 + |b|).
+
+Carve-out (DESIGN.md "parity carve-out: map_collision"): the reference's MapCollisionLoss
+gradient is chaotic at the 1-ulp level (torch.cdist's |a|^2+|b|^2-2ab form picks between tied
+nearest on-road points by rounding noise): perturbing the reference's OWN input by ~1 ulp
+changes ~25% of trajectory-steps by >1e-3.  For cases with map_collision the HIP path is
+therefore compared where the reference is stable under such perturbations (stability mask
+computed with the CPU oracle), and free-running ADE is not asserted.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import trace_oracle as orc
+from oracle.gen_golden import CASES, CHAOTIC, FULL_DIFFUSION, case_inputs, loss_component_configs
+from trace_amd import synthetic as syn
+from trace_amd.config import ModelConfig
+from trace_amd.weights import random_state_dict
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEV = "cuda:0"
+
+
+def _rel(a, b):
+    a = torch.as_tensor(a).detach().cpu().double()
+    b = torch.as_tensor(b).detach().cpu().double()
+    return float(((a - b).abs() / (1.0 + b.abs())).max())
+
+
+def _to_dev(batch):
+    return {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in batch.items()}
+
+
+@pytest.fixture(scope="module")
+def env():
+    from trace_amd import _cabi
+    from trace_amd.sampler import TraceSampler
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 0)
+    aps = [3, 2]
+    batch = syn.make_batch(cfg, aps, seed=1, extent=(0.9, 0.7, 1.75), dense=True)
+    sampler = TraceSampler(cfg, sd, DEV)
+    oracle = orc.OracleSampler(cfg, sd)
+    return dict(cfg=cfg, sd=sd, aps=aps, batch=batch, sampler=sampler, oracle=oracle,
+                lib=_cabi.lib(), cabi=_cabi)
+
+
+def test_native_library_loaded(env):
+    assert env["lib"].trace_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+def test_dynamics_rollout_and_adjoint(env):
+    cfg, s, L, cabi = env["cfg"], env["sampler"], env["lib"], env["cabi"]
+    g = torch.Generator().manual_seed(21)
+    B, N, T = 6, 3, cfg.horizon
+    M = B * N
+    for amp in (1.0, 8.0):          # amp 8 drives every clip
+        a_s = torch.randn(M, T, 2, generator=g) * amp
+        curr = torch.zeros(B, 4)
+        curr[:, 2] = torch.tensor([1.5, 29.0, -9.5, 0.02, 3.0, 12.0])
+        wgt = torch.randn(M, T, 6, generator=g)
+        a_ref = a_s.clone().requires_grad_()
+        full = orc.action_to_state_and_action(cfg, a_ref, curr.repeat_interleave(N, 0), True, True)
+        gref, = torch.autograd.grad((full * wgt).sum(), a_ref)
+        scaled = orc.scale_traj(cfg, full.detach())
+        a_d, curr_d = a_s.to(DEV), curr.to(DEV)
+        out = torch.empty(M, T, 6, device=DEV)
+        dyn = C.byref(s._dyn)
+        cabi.check(L.trace_dyn_rollout(a_d.data_ptr(), curr_d.data_ptr(), out.data_ptr(), M, N, T, 1, 0,
+                                       dyn, None))
+        assert _rel(out, full) < 1e-5
+        cabi.check(L.trace_dyn_rollout(a_d.data_ptr(), curr_d.data_ptr(), out.data_ptr(), M, N, T, 1, 1,
+                                       dyn, None))
+        assert _rel(out, scaled) < 1e-5
+        ga = torch.empty(M, T, 2, device=DEV)
+        wd = wgt.to(DEV)
+        cabi.check(L.trace_dyn_adjoint(a_d.data_ptr(), curr_d.data_ptr(), wd.data_ptr(), ga.data_ptr(), M,
+                                       N, T, dyn, None))
+        assert _rel(ga, gref) < 1e-4
+
+
+def test_map_query(env):
+    cfg, s, batch = env["cfg"], env["sampler"], env["batch"]
+    g = torch.Generator().manual_seed(22)
+    B, N = 5, 2
+    x = torch.randn(B * N, cfg.horizon, 6, generator=g)
+    x[0, :, 0] += 30.0      # far outside the raster: exercises the clamp
+    aux = s.get_aux_info(batch, True)
+    ref = orc.query_map_feats(cfg, x, batch["map_grid_feat"].repeat_interleave(N, 0),
+                              batch["raster_from_agent"].repeat_interleave(N, 0))
+    _, _, x_in, _ = s.denoise(x, 50, aux, N, w=0.0)
+    feats = x_in[:, 6:38].transpose(1, 2)
+    assert _rel(feats, ref) < 1e-5
+    assert torch.equal(x_in[:, :6].transpose(1, 2).cpu(), x)
+    assert float(x_in[:, 38:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("w", [0.0, 0.5])
+def test_denoiser_forward_and_input_vjp(env, w):
+    cfg, s, o, batch, L, cabi = (env[k] for k in ("cfg", "sampler", "oracle", "batch", "lib", "cabi"))
+    g = torch.Generator().manual_seed(23)
+    B, N = 5, 3
+    M = B * N
+    x = torch.randn(M, cfg.horizon, 6, generator=g)
+    for t in (99, 37, 0):
+        aux_o = o.repeat_aux(orc.get_aux_info(o.sd, cfg, batch, True), N)
+        xr = x.clone().requires_grad_()
+        tt = torch.full((M,), t, dtype=torch.long)
+        with torch.enable_grad():
+            _, _, x0_ref, _ = o.denoise(xr, tt, aux_o, w)
+        wgt = torch.randn(M, cfg.horizon, 2, generator=g)
+        gref, = torch.autograd.grad((x0_ref * wgt).sum(), xr)
+        aux = s.get_aux_info(batch, True)
+        x0, pred, x_in, (ws, ws_bytes) = s.denoise(x, t, aux, N, w=w, save=True)
+        # the CFG detour x0 -> eps -> x0 multiplies fp32 rounding noise of the two denoiser
+        # outputs by sqrt_recipm1_alphas_cumprod[99] ~ 2029 at t=99; x0 is
+        # then damped by posterior_mean_coef1[99] = 0.0156 before it reaches the state, which
+        # the teacher-forced step tests below check at 1e-4.
+        tol = 2e-3 if (w != 0.0 and t == 99) else 1e-4
+        assert _rel(x0, x0_ref) < tol, (t, _rel(x0, x0_ref))
+        # input VJP through CFG combine + denoiser, channels [4,5]
+        R = pred.shape[0]
+        gp = torch.empty(R, cfg.horizon, 2, device=DEV)
+        gx = torch.empty(R, cfg.horizon, 2, device=DEV)
+        sc = s._coefs(t)
+        wd = wgt.to(DEV)
+        cabi.check(L.trace_cfg_combine_adjoint(wd.data_ptr(), gp.data_ptr(),
+                                               gp[M:].data_ptr() if w else None, M, cfg.horizon, w,
+                                               C.byref(sc), None))
+        cabi.check(L.trace_unet_backward_input(s._unet, gp.data_ptr(), R, gx.data_ptr(), ws.data_ptr(),
+                                               ws_bytes, None))
+        got = gx[:M] + gx[M:] if w else gx
+        ref = gref[..., 4:6]
+        scale = float(ref.abs().max())
+        err = float((got.cpu() - ref).abs().max()) / scale
+        assert err < 2e-4, (t, err)
+
+
+def test_guidance_objectives_value_and_grad(env):
+    cfg, aps, batch = env["cfg"], env["aps"], env["batch"]
+    from trace_amd.guidance import DiffuserGuidance
+    comp = dict(np.load(os.path.join(GOLDEN, "components.npz")))
+    traj0 = torch.tensor(comp["loss/traj"])
+    B, N, T = traj0.shape[:3]
+    for lname, cfgs in loss_component_configs(batch, aps).items():
+        tr = traj0.clone().requires_grad_()
+        guid = orc.Guidance(cfgs)
+        guid.update(global_t=7)
+        tot, per = guid.loss(tr, batch)
+        gref, = torch.autograd.grad(tot, tr)
+        dg = DiffuserGuidance(cfgs)
+        dg.update(global_t=7)
+        plan = dg.build_plan(batch, N, T, DEV)
+        td = traj0.reshape(B * N, T, 6).to(DEV).contiguous()
+        gt = torch.zeros(B * N, T, 6, device=DEV)
+        ll = plan.evaluate(td, gt, None)
+        losses = plan.guide_losses(ll)
+        for k, v in per.items():
+            got = losses[k].cpu()
+            assert torch.equal(torch.isnan(got), torch.isnan(v)), (lname, k)
+            assert _rel(torch.nan_to_num(got), torch.nan_to_num(v)) < 1e-4, (lname, k)
+        scale = max(float(gref.abs().max()), 1e-12)
+        got = gt.cpu().reshape(B, N, T, 6)
+        gold = torch.tensor(comp["loss/%s/grad" % lname])
+        if lname == "map_collision":
+            # compare the cells (agent, sample, step) where the oracle agrees with itself under
+            # ~1-ulp perturbations of the input trajectory
+            pg = torch.Generator().manual_seed(5)
+            stable = torch.ones(B, N, T, dtype=torch.bool)
+            for _ in range(6):
+                trp = (traj0 * (1 + (torch.rand(traj0.shape, generator=pg) - 0.5) * 6e-7)).requires_grad_()
+                tot_p, _ = guid.loss(trp, batch)
+                gp, = torch.autograd.grad(tot_p, trp)
+                stable &= ((gp - gref).abs().amax(-1) / scale) < 1e-3
+            active = gref.abs().amax(-1) > 0
+            frac = float((stable & active).sum()) / max(float(active.sum()), 1.0)
+            assert frac > 0.3, frac
+            err = float(((got - gref).abs().amax(-1) * stable).max()) / scale
+            err_g = float(((got - gold).abs().amax(-1) * stable).max()) / scale
+            assert err < 2e-3 and err_g < 2e-3, (lname, err, err_g, frac)
+            continue
+        err = float((got - gref).abs().max()) / scale
+        err_g = float((got - gold).abs().max()) / scale      # golden (reference) values too
+        assert err < 2e-4 and err_g < 2e-4, (lname, err, err_g)
+
+
+def _run_case(env_unused, name, teacher_forced):
+    from trace_amd.sampler import TraceSampler
+    c = case_inputs(name)
+    cfg = c["cfg"]
+    s = TraceSampler(cfg, random_state_dict(cfg, c["sd_seed"]), DEV)
+    s.set_guidance(c["guidance"], c["batch"])
+    s.update_guidance(global_t=c["step_index"])
+    return c, s
+
+
+@pytest.mark.parametrize("name", sorted(FULL_DIFFUSION))
+def test_teacher_forced_steps_vs_reference_golden(name):
+    """Every reverse step started from the REFERENCE's x_t (golden diffusion chain)."""
+    c, s = _run_case(None, name, True)
+    cfg = c["cfg"]
+    gold = dict(np.load(os.path.join(GOLDEN, "sample_%s.npz" % name)))
+    d = torch.tensor(gold["diffusion_steps"])              # (B,N,T,101,6) descaled
+    B, N, T = d.shape[:3]
+    dsc = orc.scale_traj(cfg, d.reshape(B * N, -1, 6)).reshape(B * N, T, 101, 6)
+    chaotic = name in CHAOTIC
+    if chaotic:
+        o = orc.OracleSampler(cfg, random_state_dict(cfg, c["sd_seed"]))
+        o.set_guidance(c["guidance"])
+        o.guidance.update(global_t=c["step_index"])
+        aux = o.repeat_aux(orc.get_aux_info(o.sd, cfg, c["batch"], c["w"] != 0.0), N)
+        pg = torch.Generator().manual_seed(9)
+    worst, n_stable, n_out, n_tot = 0.0, 0, 0, 0
+    for k in range(cfg.n_diffusion_steps):
+        t = cfg.n_diffusion_steps - 1 - k
+        out = s.forward(c["batch"], num_samp=N, class_free_guide_w=c["w"], apply_guidance=c["apply"],
+                        guide_clean=c["clean"], x_init=dsc[:, :, k], steps=[t],
+                        noise_steps=c["noise_steps"][k:k + 1])
+        got = out["pred_traj_scaled"].reshape(B * N, T, 6).cpu()
+        ref = dsc[:, :, k + 1]
+        rel = ((got - ref).abs() / (1.0 + ref.abs())).amax(dim=(1, 2))
+        if not chaotic:
+            worst = max(worst, float(rel.max()))
+            continue
+        # stability mask: trajectories on which the reference algorithm (CPU oracle, bit-equal
+        # to the golden on the unperturbed input) reproduces itself under ~1-ulp perturbations
+        stable = torch.ones(B * N, dtype=torch.bool)
+        tt = torch.full((B * N,), t, dtype=torch.long)
+        for _ in range(4):
+            xp = dsc[:, :, k] * (1 + (torch.rand(dsc[:, :, k].shape, generator=pg) - 0.5) * 6e-7)
+            op, _ = o.p_sample(xp, tt, c["batch"], aux, N, c["w"], c["noise_steps"][k], c["apply"],
+                               c["clean"], eval_final=False)
+            stable &= ((op - ref).abs() / (1.0 + ref.abs())).amax(dim=(1, 2)) < 5e-5
+        n_tot += B * N
+        n_stable += int(stable.sum())
+        n_out += int((stable & (rel > 1e-4)).sum())
+    if not chaotic:
+        assert worst < 1e-4, worst
+    else:
+        print("stable traj-steps %d/%d, HIP outliers on stable ones %d" % (n_stable, n_tot, n_out))
+        assert n_stable > 0.3 * n_tot, (n_stable, n_tot)
+        # a flip the 4 oracle probes all missed can still occur; bound their share
+        assert n_out <= 0.02 * n_stable, (n_out, n_stable)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_free_running_sample_vs_reference_golden(name):
+    c, s = _run_case(None, name, False)
+    gold = dict(np.load(os.path.join(GOLDEN, "sample_%s.npz" % name)))
+    N = c["num_samp"]
+    out = s.forward(c["batch"], num_samp=N, return_diffusion=True, return_guidance_losses=True,
+                    class_free_guide_w=c["w"], apply_guidance=c["apply"], guide_clean=c["clean"],
+                    noise_init=c["noise_init"], noise_steps=c["noise_steps"])
+    pos = out["predictions"]["positions"].cpu()
+    assert bool(torch.isfinite(pos).all())
+    ade = float(torch.norm(pos - torch.tensor(gold["positions"]), dim=-1).mean())
+    chaotic = name in CHAOTIC
+    if not chaotic:
+        assert ade < 1e-3, ade
+    else:
+        print("free-running ADE vs golden with map_collision guidance: %.4f m (not asserted)" % ade)
+    if c["guidance"] is not None:
+        gl = out["predictions"]["guide_losses"]
+        for k in gl.keys():
+            ref = torch.tensor(gold["guide_loss/" + k])
+            got = gl[k].cpu()
+            assert torch.equal(torch.isnan(got), torch.isnan(ref)), k
+            if not chaotic:
+                tol = 2e-2 if k.startswith("map_collision") else 5e-3
+                assert _rel(torch.nan_to_num(got), torch.nan_to_num(ref)) < tol, (k, got, ref)
+        idx = out["guidance_plan"].choose_action(out["guidance_layer_losses"]).cpu().numpy()
+        if not chaotic:
+            assert np.array_equal(idx, gold["act_idx"]), (idx, gold["act_idx"])

@@ -1,0 +1,892 @@
+// Temporal UNet denoiser of TRACE on gfx950: weight packing, layer program, forward and
+// input-VJP.  Reference behaviour: tbsim/models/temporal.py:17-142,
+// tbsim/models/trace_helpers.py:17-64 (paths relative to the reference root).
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <vector>
+
+#include "conv_kernels.h"
+
+namespace trace {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// --------------------------------------------------------------------------------------
+// small kernels
+// --------------------------------------------------------------------------------------
+// Backward of GroupNorm(8) + Mish for one (row, group) per wave.
+//   da: gradient w.r.t. the Mish output; y: saved pre-norm conv output; dy: gradient w.r.t. y
+template <int L>
+__global__ __launch_bounds__(64) void gn_mish_bwd_kernel(const float* __restrict__ da,
+                                                          int da_tstride, int da_coff,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ stats,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          float* __restrict__ dy, int C, int cg,
+                                                          int rows) {
+  const int ngroups = C / cg;
+  const int row = blockIdx.x / ngroups;
+  const int g = blockIdx.x - row * ngroups;
+  if (row >= rows) return;
+  const int lane = threadIdx.x;
+  const int n = cg * L;  // <= 448
+  const float mean = stats[((size_t)row * ngroups + g) * 2];
+  const float rstd = stats[((size_t)row * ngroups + g) * 2 + 1];
+  const float* yb = y + ((size_t)row * C + g * cg) * L;
+  const float* db = da + (size_t)row * da_tstride + (size_t)(da_coff + g * cg) * L;
+  float* ob = dy + ((size_t)row * C + g * cg) * L;
+  constexpr int MAXE = 7;
+  float gg[MAXE], xh[MAXE];
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < MAXE; ++k) {
+    int e = lane + k * 64;
+    gg[k] = 0.f;
+    xh[k] = 0.f;
+    if (e < n) {
+      int c = e / L;
+      float x = (yb[e] - mean) * rstd;
+      float ga = gamma[g * cg + c];
+      float z = x * ga + beta[g * cg + c];
+      float gz = db[e] * mish_grad_f(z) * ga;
+      gg[k] = gz;
+      xh[k] = x;
+      s1 += gz;
+      s2 += gz * x;
+    }
+  }
+  const float inv_n = 1.f / (float)n;
+  s1 = wave_sum(s1) * inv_n;
+  s2 = wave_sum(s2) * inv_n;
+#pragma unroll
+  for (int k = 0; k < MAXE; ++k) {
+    int e = lane + k * 64;
+    if (e < n) ob[e] = rstd * (gg[k] - s1 - xh[k] * s2);
+  }
+}
+
+// final 1x1 conv (C -> 2) + transpose:  pred[row][t][o] = b[o] + sum_c W[o][c] f[row][c][t]
+__global__ void head_fwd_kernel(const float* __restrict__ f, const float* __restrict__ w,
+                                const float* __restrict__ b, float* __restrict__ pred, int C, int L,
+                                int rows) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * L) return;
+  int row = idx / L, t = idx - row * L;
+  const float* fb = f + (size_t)row * C * L + t;
+  float a0 = b[0], a1 = b[1];
+  for (int c = 0; c < C; ++c) {
+    float v = fb[(size_t)c * L];
+    a0 = fmaf(w[c], v, a0);
+    a1 = fmaf(w[C + c], v, a1);
+  }
+  pred[(size_t)idx * 2] = a0;
+  pred[(size_t)idx * 2 + 1] = a1;
+}
+
+// df[row][c][t] = sum_o W[o][c] g[row][t][o]
+__global__ void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
+                                float* __restrict__ df, int C, int L, int rows) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * C * L) return;
+  int row = idx / (C * L);
+  int rem = idx - row * C * L;
+  int c = rem / L, t = rem - c * L;
+  const float* gb = g + ((size_t)row * L + t) * 2;
+  df[idx] = w[c] * gb[0] + w[C + c] * gb[1];
+}
+
+// Input gradient of the first residual block restricted to input channels [c_lo, c_lo+2):
+//   gx[row][t][j] = sum_{co,tap} dy1[row][co][t+2-tap] W1[co][c_lo+j][tap] + sum_co dout[row][co][t] Wr[co][c_lo+j]
+// wsel: [2][cout][5] conv taps, rsel: [2][cout] residual 1x1 (pre-gathered on the host).
+__global__ void first_dgrad_kernel(const float* __restrict__ dy1, const float* __restrict__ dout,
+                                   const float* __restrict__ wsel, const float* __restrict__ rsel,
+                                   float* __restrict__ gx, int C, int L, int rows) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * L) return;
+  int row = idx / L, t = idx - row * L;
+  const float* yb = dy1 + (size_t)row * C * L;
+  const float* ob = dout + (size_t)row * C * L;
+  float a0 = 0.f, a1 = 0.f;
+  for (int co = 0; co < C; ++co) {
+    const float* yr = yb + (size_t)co * L;
+#pragma unroll
+    for (int tap = 0; tap < 5; ++tap) {
+      int p = t + 2 - tap;
+      if (p >= 0 && p < L) {
+        float v = yr[p];
+        a0 = fmaf(v, wsel[co * 5 + tap], a0);
+        a1 = fmaf(v, wsel[(C + co) * 5 + tap], a1);
+      }
+    }
+    float o = ob[(size_t)co * L + t];
+    a0 = fmaf(o, rsel[co], a0);
+    a1 = fmaf(o, rsel[C + co], a1);
+  }
+  gx[(size_t)idx * 2] = a0;
+  gx[(size_t)idx * 2 + 1] = a1;
+}
+
+// table[r][j] = bias[j] + sum_k W[j][k] mish(cond[r][k])
+__global__ void cond_table_kernel(const float* __restrict__ cond, const float* __restrict__ w,
+                                  const float* __restrict__ bias, float* __restrict__ table,
+                                  int cond_dim, int width, int n_rows) {
+  extern __shared__ float mc[];
+  int r = blockIdx.y;
+  for (int k = threadIdx.x; k < cond_dim; k += blockDim.x) mc[k] = mish_f(cond[(size_t)r * cond_dim + k]);
+  __syncthreads();
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= width) return;
+  const float* wr = w + (size_t)j * cond_dim;
+  float acc = 0.f;
+  for (int k = 0; k < cond_dim; ++k) acc = fmaf(wr[k], mc[k], acc);
+  table[(size_t)r * width + j] = acc + bias[j];
+}
+
+}  // namespace trace
+
+using namespace trace;
+
+// --------------------------------------------------------------------------------------
+// host-side model
+// --------------------------------------------------------------------------------------
+namespace {
+
+struct PackedConv {
+  f32x4* w = nullptr;  // device, [cout/16][nkb][64]
+  int cin = 0;         // padded
+  int cout = 0;
+  int taps = 0;
+  int chunk = 0;
+  int nkb = 0;
+};
+
+struct Block {
+  int cin, cout, L, level;
+  PackedConv c1f, c2f, rf;   // forward
+  PackedConv c1b, c2b, rb;   // input-VJP (dgrad); c1b unused for the first block
+  bool has_res;
+  float *b1, *g1, *be1, *b2, *g2, *be2, *br;
+  int emb_off;  // offset into the cond table / step table
+};
+
+struct Buf {
+  int id = -1;
+  int ctot = 0;   // channels of the underlying buffer
+  int coff = 0;
+  int L = 0;
+};
+
+}  // namespace
+
+struct trace_unet {
+  trace_unet_config cfg;
+  int cin_pad;
+  int nblocks;
+  std::vector<Block> blocks;
+  PackedConv down_f[2], down_b[2], up_f[2], up_b[2];
+  float *down_bias[2], *up_bias[2];
+  PackedConv final_f, final_b;
+  float *fb, *fg, *fbe;
+  float *head_w, *head_b;
+  float *first_wsel, *first_rsel;
+  float *condw, *condb;   // [width][cond_dim], [width]
+  float* step_table;      // [n_steps][width]
+  int width;
+  std::vector<void*> allocs;
+  // buffer plan (floats per row)
+  std::vector<int> buf_floats;
+  std::vector<char> buf_save_only;
+
+  int new_buf(int floats, bool save_only) {
+    buf_floats.push_back(floats);
+    buf_save_only.push_back(save_only ? 1 : 0);
+    return (int)buf_floats.size() - 1;
+  }
+  // ids
+  std::vector<int> b_h1, b_out, b_res, b_y1, b_y2, b_s1, b_s2;
+  int b_cat1, b_cat2, b_ds[2], b_up1, b_f, b_yf, b_sf;
+  int b_T1, b_T2, b_G0, b_G1, b_dcat1, b_dcat2;
+};
+
+namespace {
+
+template <typename T>
+int upload(trace_unet* u, const std::vector<T>& h, T** out) {
+  void* d = nullptr;
+  TRACE_CHECK_HIP(hipMalloc(&d, h.size() * sizeof(T)));
+  u->allocs.push_back(d);
+  TRACE_CHECK_HIP(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *out = reinterpret_cast<T*>(d);
+  return TRACE_OK;
+}
+
+// get(tap, ci, co) -> weight of the GEMM B matrix; ci >= cin_real returns 0.
+int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
+              const std::function<float(int, int, int)>& get, PackedConv* pc) {
+  int cin = ((cin_real + chunk - 1) / chunk) * chunk;
+  if (cin_real <= 48 && cin_real % 16 != 0) {  // first layer: 38 -> 48, single chunk
+    cin = ((cin_real + 15) / 16) * 16;
+    chunk = cin;
+  }
+  int nkb = taps * cin / 16;
+  int kbpc = chunk / 16;
+  std::vector<float> h((size_t)(cout / 16) * nkb * 64 * 4, 0.f);
+  for (int ct = 0; ct < cout / 16; ++ct) {
+    int kblk = 0;
+    for (int c0 = 0; c0 < cin; c0 += chunk)
+      for (int tap = 0; tap < taps; ++tap)
+        for (int kb = 0; kb < kbpc; ++kb, ++kblk)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int s = 0; s < 4; ++s) {
+              int ci = c0 + kb * 16 + s * 4 + (lane >> 4);
+              int co = ct * 16 + (lane & 15);
+              float v = ci < cin_real ? get(tap, ci, co) : 0.f;
+              h[(((size_t)ct * nkb + kblk) * 64 + lane) * 4 + s] = v;
+            }
+  }
+  float* d = nullptr;
+  int rc = upload(u, h, &d);
+  if (rc) return rc;
+  pc->w = reinterpret_cast<f32x4*>(d);
+  pc->cin = cin;
+  pc->cout = cout;
+  pc->taps = taps;
+  pc->chunk = chunk;
+  pc->nkb = nkb;
+  return TRACE_OK;
+}
+
+int upload_vec(trace_unet* u, const float* p, size_t n, float** out) {
+  std::vector<float> h(p, p + n);
+  return upload(u, h, out);
+}
+
+float mish_host(float x) {
+  if (x > 20.f) return x;
+  float sp = log1pf(expf(x));
+  return x * tanhf(sp);
+}
+
+struct Cursor {
+  const float* p;
+  int64_t left;
+  const float* take(int64_t n) {
+    const float* r = p;
+    p += n;
+    left -= n;
+    return r;
+  }
+};
+
+int level_of(int L, int horizon) {
+  int lv = 0;
+  while (horizon > L) { horizon /= 2; ++lv; }
+  return lv;
+}
+
+}  // namespace
+
+extern "C" const char* trace_last_error(void) { return trace::g_err; }
+extern "C" int trace_abi_version(void) { return 1; }
+
+namespace {
+struct BlockShape { int cin, cout, L; };
+std::vector<BlockShape> block_shapes(const trace_unet_config* c) {
+  std::vector<BlockShape> v;
+  int L = c->horizon;
+  int prev = c->in_channels;
+  for (int i = 0; i < c->n_levels; ++i) {
+    v.push_back({prev, c->dims[i], L});
+    v.push_back({c->dims[i], c->dims[i], L});
+    prev = c->dims[i];
+    if (i < c->n_levels - 1) L /= 2;
+  }
+  int mid = c->dims[c->n_levels - 1];
+  v.push_back({mid, mid, L});
+  v.push_back({mid, mid, L});
+  for (int i = c->n_levels - 1; i >= 1; --i) {
+    v.push_back({c->dims[i] * 2, c->dims[i - 1], L});
+    v.push_back({c->dims[i - 1], c->dims[i - 1], L});
+    L *= 2;
+  }
+  return v;
+}
+}  // namespace
+
+extern "C" int64_t trace_unet_param_count(const trace_unet_config* c) {
+  int64_t n = 0;
+  int emb = c->cond_dim + c->time_dim;
+  for (auto& b : block_shapes(c)) {
+    n += (int64_t)b.cout * emb + b.cout;
+    n += (int64_t)b.cout * b.cin * 5 + 3 * b.cout;
+    n += (int64_t)b.cout * b.cout * 5 + 3 * b.cout;
+    if (b.cin != b.cout) n += (int64_t)b.cout * b.cin + b.cout;
+  }
+  for (int i = 0; i < c->n_levels - 1; ++i) n += (int64_t)c->dims[i] * c->dims[i] * 3 + c->dims[i];
+  for (int i = c->n_levels - 2; i >= 0; --i) n += (int64_t)c->dims[i] * c->dims[i] * 4 + c->dims[i];
+  int fd = c->dims[0];
+  n += (int64_t)fd * fd * 5 + 3 * fd;
+  n += 2 * fd + 2;
+  int td = c->time_dim;
+  n += (int64_t)4 * td * td + 4 * td + (int64_t)td * 4 * td + td;
+  return n;
+}
+
+extern "C" void trace_unet_destroy(trace_unet* u) {
+  if (!u) return;
+  for (void* p : u->allocs) (void)hipFree(p);
+  delete u;
+}
+
+extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* params, int64_t n_params,
+                                 trace_unet** out) {
+  TRACE_REQUIRE(cfg && params && out, "trace_unet_create: null argument");
+  TRACE_REQUIRE(cfg->horizon == 52 && cfg->n_levels == 3, "only horizon 52 / 3 levels are built");
+  TRACE_REQUIRE(cfg->in_channels <= 48 && cfg->in_channels >= 6, "in_channels %d unsupported",
+                cfg->in_channels);
+  for (int i = 0; i < 3; ++i)
+    TRACE_REQUIRE(cfg->dims[i] % 64 == 0 && (cfg->dims[i] / cfg->n_groups) > 0 &&
+                      64 % (cfg->dims[i] / cfg->n_groups) == 0,
+                  "level %d channels %d unsupported", i, cfg->dims[i]);
+  TRACE_REQUIRE(cfg->n_groups == 8, "n_groups must be 8");
+  TRACE_REQUIRE(n_params == trace_unet_param_count(cfg), "expected %lld parameters, got %lld",
+                (long long)trace_unet_param_count(cfg), (long long)n_params);
+  trace_unet* u = new trace_unet();
+  u->cfg = *cfg;
+  u->cin_pad = 48;
+  Cursor cur{params, n_params};
+  const int emb = cfg->cond_dim + cfg->time_dim;
+  const int td = cfg->time_dim;
+  auto shapes = block_shapes(cfg);
+  u->nblocks = (int)shapes.size();
+  int rc = TRACE_OK;
+  std::vector<const float*> tw_ptrs;   // time_mlp.1.weight per block (host)
+  std::vector<float> condw, condb;
+  int width = 0;
+  const float* first_w1 = nullptr;
+  const float* first_wr = nullptr;
+#define TRY(x)                      \
+  do {                              \
+    rc = (x);                       \
+    if (rc) {                       \
+      trace_unet_destroy(u);        \
+      return rc;                    \
+    }                               \
+  } while (0)
+  for (size_t bi = 0; bi < shapes.size(); ++bi) {
+    Block b{};
+    b.cin = shapes[bi].cin;
+    b.cout = shapes[bi].cout;
+    b.L = shapes[bi].L;
+    b.level = level_of(b.L, cfg->horizon);
+    b.has_res = b.cin != b.cout;
+    b.emb_off = width;
+    width += b.cout;
+    const float* tw = cur.take((int64_t)b.cout * emb);
+    const float* tb = cur.take(b.cout);
+    tw_ptrs.push_back(tw);
+    for (int co = 0; co < b.cout; ++co) {
+      for (int k = 0; k < cfg->cond_dim; ++k) condw.push_back(tw[(size_t)co * emb + td + k]);
+      condb.push_back(tb[co]);
+    }
+    const float* w1 = cur.take((int64_t)b.cout * b.cin * 5);
+    const float* b1 = cur.take(b.cout);
+    const float* g1 = cur.take(b.cout);
+    const float* be1 = cur.take(b.cout);
+    const float* w2 = cur.take((int64_t)b.cout * b.cout * 5);
+    const float* b2 = cur.take(b.cout);
+    const float* g2 = cur.take(b.cout);
+    const float* be2 = cur.take(b.cout);
+    const int ci_ = b.cin, co_ = b.cout;
+    TRY(pack_conv(u, ci_, co_, 5, 64, [=](int tap, int ci, int co) { return w1[((size_t)co * ci_ + ci) * 5 + tap]; }, &b.c1f));
+    TRY(pack_conv(u, co_, co_, 5, 64, [=](int tap, int ci, int co) { return w2[((size_t)co * co_ + ci) * 5 + tap]; }, &b.c2f));
+    // dgrad: K runs over (tap', co), output channel = ci, weight W[co][ci][4 - tap']
+    TRY(pack_conv(u, co_, co_, 5, 64, [=](int tap, int k, int n) { return w2[((size_t)k * co_ + n) * 5 + (4 - tap)]; }, &b.c2b));
+    if (bi > 0)
+      TRY(pack_conv(u, co_, ci_, 5, 64, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b));
+    else
+      first_w1 = w1;
+    TRY(upload_vec(u, b1, co_, &b.b1));
+    TRY(upload_vec(u, g1, co_, &b.g1));
+    TRY(upload_vec(u, be1, co_, &b.be1));
+    TRY(upload_vec(u, b2, co_, &b.b2));
+    TRY(upload_vec(u, g2, co_, &b.g2));
+    TRY(upload_vec(u, be2, co_, &b.be2));
+    if (b.has_res) {
+      const float* wr = cur.take((int64_t)co_ * ci_);
+      const float* br = cur.take(co_);
+      TRY(pack_conv(u, ci_, co_, 1, 64, [=](int, int ci, int co) { return wr[(size_t)co * ci_ + ci]; }, &b.rf));
+      if (bi > 0)
+        TRY(pack_conv(u, co_, ci_, 1, 64, [=](int, int k, int n) { return wr[(size_t)k * ci_ + n]; }, &b.rb));
+      else
+        first_wr = wr;
+      TRY(upload_vec(u, br, co_, &b.br));
+    }
+    u->blocks.push_back(b);
+  }
+  TRACE_REQUIRE(first_w1 && first_wr, "first block must change channel count");
+  // down-sample convs (Conv1d k3 s2 p1), weight (c, c, 3)
+  for (int i = 0; i < 2; ++i) {
+    int c = cfg->dims[i];
+    const float* w = cur.take((int64_t)c * c * 3);
+    const float* b = cur.take(c);
+    TRY(pack_conv(u, c, c, 3, 32, [=](int tap, int ci, int co) { return w[((size_t)co * c + ci) * 3 + tap]; }, &u->down_f[i]));
+    TRY(pack_conv(u, c, c, 3, 64, [=](int tap, int k, int n) { return w[((size_t)k * c + n) * 3 + (2 - tap)]; }, &u->down_b[i]));
+    TRY(upload_vec(u, b, c, &u->down_bias[i]));
+  }
+  // up-sample convs (ConvTranspose1d k4 s2 p1), weight (in, out, 4); ups.0 is the deepest
+  for (int i = 0; i < 2; ++i) {
+    int c = cfg->dims[1 - i];
+    const float* w = cur.take((int64_t)c * c * 4);
+    const float* b = cur.take(c);
+    TRY(pack_conv(u, c, c, 4, 64, [=](int tap, int ci, int co) { return w[((size_t)ci * c + co) * 4 + (3 - tap)]; }, &u->up_f[i]));
+    TRY(pack_conv(u, c, c, 4, 32, [=](int tap, int k, int n) { return w[((size_t)n * c + k) * 4 + tap]; }, &u->up_b[i]));
+    TRY(upload_vec(u, b, c, &u->up_bias[i]));
+  }
+  {
+    int c = cfg->dims[0];
+    const float* w = cur.take((int64_t)c * c * 5);
+    const float* b = cur.take(c);
+    const float* g = cur.take(c);
+    const float* be = cur.take(c);
+    TRY(pack_conv(u, c, c, 5, 64, [=](int tap, int ci, int co) { return w[((size_t)co * c + ci) * 5 + tap]; }, &u->final_f));
+    TRY(pack_conv(u, c, c, 5, 64, [=](int tap, int k, int n) { return w[((size_t)k * c + n) * 5 + (4 - tap)]; }, &u->final_b));
+    TRY(upload_vec(u, b, c, &u->fb));
+    TRY(upload_vec(u, g, c, &u->fg));
+    TRY(upload_vec(u, be, c, &u->fbe));
+    const float* hw = cur.take(2 * c);
+    const float* hb = cur.take(2);
+    TRY(upload_vec(u, hw, 2 * c, &u->head_w));
+    TRY(upload_vec(u, hb, 2, &u->head_b));
+  }
+  // first-block input gradient for trajectory channels [4,5]
+  {
+    int c = cfg->dims[0], ci_ = cfg->in_channels;
+    std::vector<float> wsel((size_t)2 * c * 5), rsel((size_t)2 * c);
+    for (int j = 0; j < 2; ++j)
+      for (int co = 0; co < c; ++co) {
+        for (int tap = 0; tap < 5; ++tap)
+          wsel[((size_t)j * c + co) * 5 + tap] = first_w1[((size_t)co * ci_ + 4 + j) * 5 + tap];
+        rsel[(size_t)j * c + co] = first_wr[(size_t)co * ci_ + 4 + j];
+      }
+    TRY(upload(u, wsel, &u->first_wsel));
+    TRY(upload(u, rsel, &u->first_rsel));
+  }
+  // time MLP -> per-step additive table  (temporal.py:68-74,122; trace_helpers.py:17-29)
+  {
+    const float* w1 = cur.take((int64_t)4 * td * td);
+    const float* b1 = cur.take(4 * td);
+    const float* w3 = cur.take((int64_t)td * 4 * td);
+    const float* b3 = cur.take(td);
+    std::vector<float> table((size_t)cfg->n_steps * width, 0.f);
+    int half = td / 2;
+    float fr = logf(10000.f) / (float)(half - 1);
+    for (int t = 0; t < cfg->n_steps; ++t) {
+      std::vector<float> e(td), h(4 * td), te(td);
+      for (int i = 0; i < half; ++i) {
+        float f = expf((float)i * -fr);
+        float a = (float)t * f;
+        e[i] = sinf(a);
+        e[half + i] = cosf(a);
+      }
+      for (int j = 0; j < 4 * td; ++j) {
+        float acc = 0.f;
+        for (int k = 0; k < td; ++k) acc = fmaf(w1[(size_t)j * td + k], e[k], acc);
+        h[j] = mish_host(acc + b1[j]);
+      }
+      for (int j = 0; j < td; ++j) {
+        float acc = 0.f;
+        for (int k = 0; k < 4 * td; ++k) acc = fmaf(w3[(size_t)j * 4 * td + k], h[k], acc);
+        te[j] = mish_host(acc + b3[j]);   // the per-block Linear sees mish(emb)
+      }
+      for (size_t bi = 0; bi < u->blocks.size(); ++bi) {
+        const Block& b = u->blocks[bi];
+        const float* tw = tw_ptrs[bi];
+        for (int co = 0; co < b.cout; ++co) {
+          float acc = 0.f;
+          for (int k = 0; k < td; ++k) acc = fmaf(tw[(size_t)co * emb + k], te[k], acc);
+          table[(size_t)t * width + b.emb_off + co] = acc;
+        }
+      }
+    }
+    TRY(upload(u, table, &u->step_table));
+  }
+  TRACE_REQUIRE(cur.left == 0, "parameter blob not fully consumed (%lld left)", (long long)cur.left);
+  u->width = width;
+  TRY(upload(u, condw, &u->condw));
+  TRY(upload(u, condb, &u->condb));
+#undef TRY
+
+  // ---- buffer plan -------------------------------------------------------------------
+  const int H = cfg->horizon;
+  const int d0 = cfg->dims[0], d1 = cfg->dims[1], d2 = cfg->dims[2];
+  u->b_cat1 = u->new_buf(2 * d1 * (H / 2), false);
+  u->b_cat2 = u->new_buf(2 * d2 * (H / 4), false);
+  u->b_ds[0] = u->new_buf(d0 * (H / 2), false);
+  u->b_ds[1] = u->new_buf(d1 * (H / 4), false);
+  u->b_up1 = u->new_buf(d0 * H, false);
+  u->b_f = u->new_buf(d0 * H, false);
+  u->b_yf = u->new_buf(d0 * H, true);
+  u->b_sf = u->new_buf(16, true);
+  for (auto& b : u->blocks) {
+    u->b_h1.push_back(u->new_buf(b.cout * b.L, false));
+    u->b_out.push_back(u->new_buf(b.cout * b.L, false));
+    u->b_res.push_back(b.has_res ? u->new_buf(b.cout * b.L, false) : -1);
+    u->b_y1.push_back(u->new_buf(b.cout * b.L, true));
+    u->b_y2.push_back(u->new_buf(b.cout * b.L, true));
+    u->b_s1.push_back(u->new_buf(16, true));
+    u->b_s2.push_back(u->new_buf(16, true));
+  }
+  int gmax = d0 * H;
+  if (d1 * (H / 2) > gmax) gmax = d1 * (H / 2);
+  if (d2 * (H / 4) > gmax) gmax = d2 * (H / 4);
+  u->b_T1 = u->new_buf(gmax, true);
+  u->b_T2 = u->new_buf(gmax, true);
+  u->b_G0 = u->new_buf(gmax, true);
+  u->b_G1 = u->new_buf(gmax, true);
+  u->b_dcat1 = u->new_buf(2 * d1 * (H / 2), true);
+  u->b_dcat2 = u->new_buf(2 * d2 * (H / 4), true);
+  *out = u;
+  return TRACE_OK;
+}
+
+extern "C" int trace_unet_cond_width(const trace_unet* u) { return u ? u->width : 0; }
+
+extern "C" int trace_unet_cond_table(const trace_unet* u, const float* cond, int n_rows,
+                                     float* table, void* stream) {
+  TRACE_REQUIRE(u && cond && table && n_rows >= 0, "trace_unet_cond_table: bad argument");
+  if (n_rows == 0) return TRACE_OK;
+  dim3 grid((u->width + 255) / 256, n_rows);
+  hipLaunchKernelGGL(cond_table_kernel, grid, dim3(256), u->cfg.cond_dim * sizeof(float),
+                     (hipStream_t)stream, cond, u->condw, u->condb, table, u->cfg.cond_dim, u->width,
+                     n_rows);
+  return launch_status("cond_table_kernel");
+}
+
+namespace {
+
+struct Layout {
+  std::vector<int64_t> off;  // float offsets
+  int64_t total = 0;
+};
+
+Layout make_layout(const trace_unet* u, int rows, int save) {
+  Layout l;
+  l.off.resize(u->buf_floats.size(), -1);
+  int64_t o = 0;
+  for (size_t i = 0; i < u->buf_floats.size(); ++i) {
+    if (u->buf_save_only[i] && !save) continue;
+    l.off[i] = o;
+    int64_t n = (int64_t)u->buf_floats[i] * rows;
+    o += (n + 63) / 64 * 64;
+  }
+  l.total = o;
+  return l;
+}
+
+enum ConvKind { K_CONV5, K_CONV1, K_DOWN_F, K_UP_F, K_DOWN_B, K_UP_B };
+
+int run_conv(ConvKind kind, int L_out, const ConvArgs& a, hipStream_t st) {
+  switch (kind) {
+    case K_CONV5:
+      if (L_out == 52) return launch_conv<52, 1, 1, 5, 2, 4>(a, st);
+      if (L_out == 26) return launch_conv<26, 1, 1, 5, 2, 8>(a, st);
+      if (L_out == 13) return launch_conv<13, 1, 1, 5, 2, 16>(a, st);
+      break;
+    case K_CONV1:
+      if (L_out == 52) return launch_conv<52, 1, 1, 1, 0, 4>(a, st);
+      if (L_out == 26) return launch_conv<26, 1, 1, 1, 0, 8>(a, st);
+      if (L_out == 13) return launch_conv<13, 1, 1, 1, 0, 16>(a, st);
+      break;
+    case K_DOWN_F:
+      if (L_out == 26) return launch_conv<26, 2, 1, 3, 1, 8>(a, st);
+      if (L_out == 13) return launch_conv<13, 2, 1, 3, 1, 16>(a, st);
+      break;
+    case K_UP_F:
+      if (L_out == 26) return launch_conv<26, 1, 2, 4, 2, 8>(a, st);
+      if (L_out == 52) return launch_conv<52, 1, 2, 4, 2, 4>(a, st);
+      break;
+    case K_DOWN_B:
+      if (L_out == 52) return launch_conv<52, 1, 2, 3, 1, 4>(a, st);
+      if (L_out == 26) return launch_conv<26, 1, 2, 3, 1, 8>(a, st);
+      break;
+    case K_UP_B:
+      if (L_out == 13) return launch_conv<13, 2, 1, 4, 1, 16>(a, st);
+      if (L_out == 26) return launch_conv<26, 2, 1, 4, 1, 8>(a, st);
+      break;
+  }
+  set_error("no conv kernel for kind %d L_out %d", (int)kind, L_out);
+  return TRACE_EINVAL;
+}
+
+struct View {
+  float* p;
+  int ctot;
+  int coff;
+  int L;
+  int tstride() const { return ctot * L; }
+};
+
+ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const View& out,
+                   int rows) {
+  ConvArgs a{};
+  a.in = in.p;
+  a.in_tstride = in.tstride();
+  a.in_coff = in.coff;
+  a.cin = w.cin;
+  a.chunk = w.chunk;
+  a.wp = w.w;
+  a.nkb = w.nkb;
+  a.bias = bias;
+  a.out = out.p;
+  a.out_tstride = out.tstride();
+  a.out_coff = out.coff;
+  a.cout = w.cout;
+  a.rows = rows;
+  return a;
+}
+
+void set_res(ConvArgs& a, const View& r) {
+  a.res = r.p;
+  a.res_tstride = r.tstride();
+  a.res_coff = r.coff;
+}
+void set_res2(ConvArgs& a, const View& r) {
+  a.res2 = r.p;
+  a.res2_tstride = r.tstride();
+  a.res2_coff = r.coff;
+}
+
+int run_gn_bwd(const View& da, const float* y, const float* stats, const float* gamma,
+               const float* beta, float* dy, int C, int L, int rows, hipStream_t st) {
+  int cg = C / 8;
+  dim3 grid(rows * 8);
+#define GNB(LL)                                                                              \
+  hipLaunchKernelGGL(gn_mish_bwd_kernel<LL>, grid, dim3(64), 0, st, da.p, da.tstride(), da.coff, \
+                     y, stats, gamma, beta, dy, C, cg, rows)
+  if (L == 52) GNB(52);
+  else if (L == 26) GNB(26);
+  else if (L == 13) GNB(13);
+  else {
+    set_error("gn bwd: L=%d", L);
+    return TRACE_EINVAL;
+  }
+#undef GNB
+  return launch_status("gn_mish_bwd_kernel");
+}
+
+}  // namespace
+
+extern "C" int64_t trace_unet_workspace_bytes(const trace_unet* u, int rows, int save) {
+  if (!u || rows < 0) return 0;
+  return make_layout(u, rows, save).total * (int64_t)sizeof(float);
+}
+
+#define RUN(x)           \
+  do {                   \
+    int _rc = (x);       \
+    if (_rc) return _rc; \
+  } while (0)
+
+extern "C" int trace_unet_forward(trace_unet* u, const float* x_in, const float* cond_table,
+                                  int rows_per_cond, int step, int rows, float* pred,
+                                  void* workspace, int64_t workspace_bytes, int save,
+                                  void* stream) {
+  TRACE_REQUIRE(u && x_in && cond_table && pred && workspace, "trace_unet_forward: null argument");
+  TRACE_REQUIRE(rows >= 0 && rows_per_cond > 0, "trace_unet_forward: rows=%d rows_per_cond=%d", rows,
+                rows_per_cond);
+  TRACE_REQUIRE(step >= 0 && step < u->cfg.n_steps, "step %d out of range", step);
+  if (rows == 0) return TRACE_OK;
+  Layout lay = make_layout(u, rows, save);
+  if (lay.total * (int64_t)sizeof(float) > workspace_bytes) {
+    set_error("workspace too small: need %lld bytes, have %lld", (long long)lay.total * 4,
+              (long long)workspace_bytes);
+    return TRACE_ENOMEM;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = reinterpret_cast<float*>(workspace);
+  auto buf = [&](int id) -> float* { return id >= 0 && lay.off[id] >= 0 ? ws + lay.off[id] : nullptr; };
+  const trace_unet_config& c = u->cfg;
+  const int H = c.horizon;
+  const float* pt = u->step_table + (size_t)step * u->width;
+
+  // views of each block's input / output (skip concatenation is done by writing in place)
+  auto whole = [&](int id, int C, int L) { return View{buf(id), C, 0, L}; };
+  std::vector<View> bin(u->nblocks), bout(u->nblocks);
+  const int d0 = c.dims[0], d1 = c.dims[1], d2 = c.dims[2];
+  View cat1{buf(u->b_cat1), 2 * d1, 0, H / 2}, cat2{buf(u->b_cat2), 2 * d2, 0, H / 4};
+  // block order: d0.0 d0.1 d1.0 d1.1 d2.0 d2.1 mid1 mid2 u0.0 u0.1 u1.0 u1.1
+  bin[0] = View{const_cast<float*>(x_in), u->cin_pad, 0, H};
+  for (int i = 0; i < u->nblocks; ++i) bout[i] = whole(u->b_out[i], u->blocks[i].cout, u->blocks[i].L);
+  bout[3] = View{cat1.p, cat1.ctot, d1, cat1.L};   // d1.1 -> skip half of cat1
+  bout[5] = View{cat2.p, cat2.ctot, d2, cat2.L};   // d2.1 -> skip half of cat2
+  bout[7] = View{cat2.p, cat2.ctot, 0, cat2.L};    // mid2 -> first half of cat2
+  bin[1] = bout[0];
+  bin[2] = whole(u->b_ds[0], d0, H / 2);
+  bin[3] = bout[2];
+  bin[4] = whole(u->b_ds[1], d1, H / 4);
+  bin[5] = bout[4];
+  bin[6] = bout[5];
+  bin[7] = bout[6];
+  bin[8] = cat2;
+  bin[9] = bout[8];
+  bin[10] = cat1;
+  bin[11] = bout[10];
+
+  auto res_block = [&](int i) -> int {
+    const Block& b = u->blocks[i];
+    View h1 = whole(u->b_h1[i], b.cout, b.L);
+    ConvArgs a = conv_args(bin[i], b.c1f, b.b1, h1, rows);
+    a.gn = 1; a.cg = b.cout / 8; a.gamma = b.g1; a.beta = b.be1;
+    a.pc = cond_table; a.pc_stride = u->width; a.pc_off = b.emb_off; a.rows_per_cond = rows_per_cond;
+    a.pt = pt + b.emb_off;
+    if (save) { a.ysave = buf(u->b_y1[i]); a.stats = buf(u->b_s1[i]); }
+    RUN(run_conv(K_CONV5, b.L, a, st));
+    View r = bin[i];
+    if (b.has_res) {
+      r = whole(u->b_res[i], b.cout, b.L);
+      ConvArgs ar = conv_args(bin[i], b.rf, b.br, r, rows);
+      RUN(run_conv(K_CONV1, b.L, ar, st));
+    }
+    ConvArgs a2 = conv_args(h1, b.c2f, b.b2, bout[i], rows);
+    a2.gn = 1; a2.cg = b.cout / 8; a2.gamma = b.g2; a2.beta = b.be2;
+    set_res(a2, r);
+    if (save) { a2.ysave = buf(u->b_y2[i]); a2.stats = buf(u->b_s2[i]); }
+    RUN(run_conv(K_CONV5, b.L, a2, st));
+    return TRACE_OK;
+  };
+
+  RUN(res_block(0));
+  RUN(res_block(1));
+  RUN(run_conv(K_DOWN_F, H / 2, conv_args(bout[1], u->down_f[0], u->down_bias[0], bin[2], rows), st));
+  RUN(res_block(2));
+  RUN(res_block(3));
+  RUN(run_conv(K_DOWN_F, H / 4, conv_args(bout[3], u->down_f[1], u->down_bias[1], bin[4], rows), st));
+  RUN(res_block(4));
+  RUN(res_block(5));
+  RUN(res_block(6));
+  RUN(res_block(7));
+  RUN(res_block(8));
+  RUN(res_block(9));
+  RUN(run_conv(K_UP_F, H / 2,
+               conv_args(bout[9], u->up_f[0], u->up_bias[0], View{cat1.p, cat1.ctot, 0, cat1.L}, rows), st));
+  RUN(res_block(10));
+  RUN(res_block(11));
+  View up1 = whole(u->b_up1, d0, H);
+  RUN(run_conv(K_UP_F, H, conv_args(bout[11], u->up_f[1], u->up_bias[1], up1, rows), st));
+  View f = whole(u->b_f, d0, H);
+  {
+    ConvArgs a = conv_args(up1, u->final_f, u->fb, f, rows);
+    a.gn = 1; a.cg = d0 / 8; a.gamma = u->fg; a.beta = u->fbe;
+    if (save) { a.ysave = buf(u->b_yf); a.stats = buf(u->b_sf); }
+    RUN(run_conv(K_CONV5, H, a, st));
+  }
+  {
+    int n = rows * H;
+    hipLaunchKernelGGL(head_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, f.p, u->head_w,
+                       u->head_b, pred, d0, H, rows);
+    RUN(launch_status("head_fwd_kernel"));
+  }
+  return TRACE_OK;
+}
+
+extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, int rows,
+                                         float* grad_x, void* workspace, int64_t workspace_bytes,
+                                         void* stream) {
+  TRACE_REQUIRE(u && grad_pred && grad_x && workspace, "trace_unet_backward_input: null argument");
+  if (rows <= 0) return TRACE_OK;
+  Layout lay = make_layout(u, rows, 1);
+  if (lay.total * (int64_t)sizeof(float) > workspace_bytes) {
+    set_error("workspace too small for backward: need %lld bytes, have %lld",
+              (long long)lay.total * 4, (long long)workspace_bytes);
+    return TRACE_ENOMEM;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = reinterpret_cast<float*>(workspace);
+  auto buf = [&](int id) -> float* { return ws + lay.off[id]; };
+  const trace_unet_config& c = u->cfg;
+  const int H = c.horizon;
+  const int d0 = c.dims[0], d1 = c.dims[1], d2 = c.dims[2];
+  float *T1 = buf(u->b_T1), *T2 = buf(u->b_T2), *G0 = buf(u->b_G0), *G1 = buf(u->b_G1);
+  View dcat1{buf(u->b_dcat1), 2 * d1, 0, H / 2}, dcat2{buf(u->b_dcat2), 2 * d2, 0, H / 4};
+
+  // backward of one residual block: dout -> dx (+ optional extra addend), see DESIGN.md
+  auto block_bwd = [&](int i, const View& dout, const View& dx, const View* extra) -> int {
+    const Block& b = u->blocks[i];
+    View t1{T1, b.cout, 0, b.L}, t2{T2, b.cout, 0, b.L};
+    RUN(run_gn_bwd(dout, buf(u->b_y2[i]), buf(u->b_s2[i]), b.g2, b.be2, T1, b.cout, b.L, rows, st));
+    RUN(run_conv(K_CONV5, b.L, conv_args(t1, b.c2b, nullptr, t2, rows), st));
+    RUN(run_gn_bwd(t2, buf(u->b_y1[i]), buf(u->b_s1[i]), b.g1, b.be1, T1, b.cout, b.L, rows, st));
+    ConvArgs a = conv_args(t1, b.c1b, nullptr, dx, rows);
+    if (!b.has_res) set_res(a, dout);
+    if (extra) set_res2(a, *extra);
+    RUN(run_conv(K_CONV5, b.L, a, st));
+    if (b.has_res) {
+      ConvArgs ar = conv_args(dout, b.rb, nullptr, dx, rows);
+      set_res(ar, dx);
+      RUN(run_conv(K_CONV1, b.L, ar, st));
+    }
+    return TRACE_OK;
+  };
+
+  // head + final block
+  {
+    int n = rows * d0 * H;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, grad_pred,
+                       u->head_w, G0, d0, H, rows);
+    RUN(launch_status("head_bwd_kernel"));
+    View g0{G0, d0, 0, H}, t1{T1, d0, 0, H}, g1{G1, d0, 0, H};
+    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, T1, d0, H, rows, st));
+    RUN(run_conv(K_CONV5, H, conv_args(t1, u->final_b, nullptr, g1, rows), st));
+  }
+  // up1 (ConvT d0: L/2 -> L)
+  RUN(run_conv(K_UP_B, H / 2, conv_args(View{G1, d0, 0, H}, u->up_b[1], nullptr, View{G0, d0, 0, H / 2}, rows), st));
+  RUN(block_bwd(11, View{G0, d0, 0, H / 2}, View{G1, d0, 0, H / 2}, nullptr));
+  RUN(block_bwd(10, View{G1, d0, 0, H / 2}, dcat1, nullptr));
+  // up0 (ConvT d1: L/4 -> L/2) reads the first half of dcat1
+  RUN(run_conv(K_UP_B, H / 4, conv_args(View{dcat1.p, dcat1.ctot, 0, dcat1.L}, u->up_b[0], nullptr,
+                                         View{G0, d1, 0, H / 4}, rows), st));
+  RUN(block_bwd(9, View{G0, d1, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr));
+  RUN(block_bwd(8, View{G1, d1, 0, H / 4}, dcat2, nullptr));
+  // mid2: dout = dcat2[0:d2]
+  RUN(block_bwd(7, View{dcat2.p, dcat2.ctot, 0, dcat2.L}, View{G0, d2, 0, H / 4}, nullptr));
+  // mid1: + skip gradient dcat2[d2:2*d2]
+  {
+    View skip{dcat2.p, dcat2.ctot, d2, dcat2.L};
+    RUN(block_bwd(6, View{G0, d2, 0, H / 4}, View{G1, d2, 0, H / 4}, &skip));
+  }
+  RUN(block_bwd(5, View{G1, d2, 0, H / 4}, View{G0, d2, 0, H / 4}, nullptr));
+  RUN(block_bwd(4, View{G0, d2, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr));
+  // down1 (Conv k3 s2 d1: L/2 -> L/4) + skip gradient dcat1[d1:2*d1]
+  {
+    ConvArgs a = conv_args(View{G1, d1, 0, H / 4}, u->down_b[1], nullptr, View{G0, d1, 0, H / 2}, rows);
+    set_res(a, View{dcat1.p, dcat1.ctot, d1, dcat1.L});
+    RUN(run_conv(K_DOWN_B, H / 2, a, st));
+  }
+  RUN(block_bwd(3, View{G0, d1, 0, H / 2}, View{G1, d1, 0, H / 2}, nullptr));
+  RUN(block_bwd(2, View{G1, d1, 0, H / 2}, View{G0, d0, 0, H / 2}, nullptr));
+  // down0 (Conv k3 s2 d0: L -> L/2); the level-0 skip is never consumed (temporal.py:129,134)
+  RUN(run_conv(K_DOWN_B, H, conv_args(View{G0, d0, 0, H / 2}, u->down_b[0], nullptr, View{G1, d0, 0, H}, rows), st));
+  RUN(block_bwd(1, View{G1, d0, 0, H}, View{G0, d0, 0, H}, nullptr));
+  // first block: only input channels [4,5] are needed (tbsim/models/trace.py:674-676)
+  {
+    const Block& b = u->blocks[0];
+    View dout{G0, d0, 0, H};
+    RUN(run_gn_bwd(dout, buf(u->b_y2[0]), buf(u->b_s2[0]), b.g2, b.be2, T1, b.cout, b.L, rows, st));
+    RUN(run_conv(K_CONV5, b.L, conv_args(View{T1, d0, 0, H}, b.c2b, nullptr, View{T2, d0, 0, H}, rows), st));
+    RUN(run_gn_bwd(View{T2, d0, 0, H}, buf(u->b_y1[0]), buf(u->b_s1[0]), b.g1, b.be1, T1, b.cout, b.L, rows, st));
+    int n = rows * H;
+    hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, T1, G0,
+                       u->first_wsel, u->first_rsel, grad_x, d0, H, rows);
+    RUN(launch_status("first_dgrad_kernel"));
+  }
+  return TRACE_OK;
+}
