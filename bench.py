@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Benchmark of the TRACE guided sampler on MI355X (contract: see the round prompt / DESIGN.md).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE full sampling call of the hot path over one batch: 100 DDPM steps x 52-step
+horizon through ``DiffuserTrafficModel.get_action`` (conditioning, denoiser forward + input-VJP,
+guidance, posterior/dynamics, sample selection), inputs resident in HBM.  Workload = BASELINE.json
+configs[1]: target_pos guidance + classifier-free guidance (w=0.5), 256 agents x 20 samples,
+clean guidance, per GPU (weak scaling: every rank owns its own scenes; the only exchange is the
+all-gather of scores / selected plans at the end of each call).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from trace_amd import synthetic as syn                    # noqa: E402
+from trace_amd.config import ModelConfig                  # noqa: E402
+from trace_amd.weights import random_state_dict           # noqa: E402
+
+WORKLOADS = {
+    # name: (scenes, agents per scene, samples, guidance kind, cfg w, clean)
+    "cfg2_target_pos_cfg_clean": dict(scenes=8, agents=32, samples=20, guide="target_pos", w=0.5,
+                                      clean=True, dense=False),
+    "cfg1_unguided": dict(scenes=1, agents=16, samples=20, guide=None, w=0.0, clean=False, dense=False),
+    "cfg3_dense_collision": dict(scenes=1, agents=128, samples=20, guide="collision", w=0.0,
+                                 clean=True, dense=True),
+}
+
+
+def build_inputs(cfg, wl, seed, device):
+    aps = [wl["agents"]] * wl["scenes"]
+    batch = syn.make_batch(cfg, aps, seed=seed, dense=wl["dense"], max_neighbors=16)
+    guidance = None
+    if wl["guide"] == "target_pos":
+        guidance = syn.target_pos_guidance(batch, aps, weight=30000.0, seed=seed)
+    elif wl["guide"] == "collision":
+        guidance = syn.collision_guidance(aps, agent_weight=1000.0, map_weight=10.0, num_disks=1)
+    if device is not None:
+        batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
+    return aps, batch, guidance
+
+
+def cpu_baseline(cfg, sd, wl_name, seconds_hint=20.0):
+    """The CPU oracle (port of the reference's algorithm, oracle/trace_oracle.py) timed on this
+    host's cores on a bounded sample of the same workload: 16 agents x 20 samples, a few of the
+    100 DDPM steps, scaled to a full call."""
+    from oracle import trace_oracle as orc
+    wl = dict(WORKLOADS[wl_name])
+    wl["scenes"], wl["agents"] = 1, 16
+    aps, batch, guidance = build_inputs(cfg, wl, 1234, None)
+    o = orc.OracleSampler(cfg, sd)
+    o.set_guidance(guidance)
+    N = wl["samples"]
+    M = sum(aps) * N
+    # warm-up (thread pools, oneDNN primitive caches), then size the sample for ~seconds_hint
+    o.sample(batch, N, wl["w"], True, wl["clean"], n_steps=1, return_diffusion=False)
+    t0 = time.perf_counter()
+    o.sample(batch, N, wl["w"], True, wl["clean"], n_steps=2, return_diffusion=False)
+    per_step = (time.perf_counter() - t0) / 2
+    n_steps = int(max(4, min(cfg.n_diffusion_steps, seconds_hint / max(per_step, 1e-3))))
+    t0 = time.perf_counter()
+    o.sample(batch, N, wl["w"], True, wl["clean"], n_steps=n_steps, return_diffusion=False)
+    dt = time.perf_counter() - t0
+    full = dt * cfg.n_diffusion_steps / n_steps
+    return {"value": M / full, "unit": "trajectories/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%d agents x %d samples (M=%d), %d of %d DDPM steps timed (%.1f s), scaled to a "
+                      "full call" % (sum(aps), N, M, n_steps, cfg.n_diffusion_steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cfg2_target_pos_cfg_clean", choices=sorted(WORKLOADS))
+    ap.add_argument("--scenes", type=int, default=None, help="override scenes per GPU (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from trace_amd import _cabi
+    from trace_amd.distributed import gather_actions
+    from trace_amd.policy import DiffuserTrafficModel, PolicyWrapper
+
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 0)
+    wl = dict(WORKLOADS[args.workload])
+    if args.scenes is not None:
+        wl["scenes"] = args.scenes
+    aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, device)
+    N = wl["samples"]
+    B = sum(aps)
+    M = B * N
+
+    model = DiffuserTrafficModel(cfg, sd, device)
+    policy = PolicyWrapper.wrap_controller(model, num_action_samples=N, class_free_guide_w=wl["w"],
+                                           guide_as_filter_only=False, guide_with_gt=False,
+                                           guide_clean=wl["clean"])
+    if guidance is not None:
+        model.set_guidance(guidance, batch)
+    gen = torch.Generator(device=device).manual_seed(7 + rank)
+
+    def one_step(i):
+        action, info = policy.get_action(batch, step_index=i, generator=gen)
+        scores = info.get("guide_scores")
+        if scores is None:
+            scores = torch.zeros(B, N, device=device)
+        # the path's one exchange step (RCCL all-gather; a no-op on one GPU)
+        return gather_actions(action.positions, action.yaws, scores, info["act_idx"])
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert bool(torch.isfinite(out[0]).all()), "non-finite plan"
+
+    roofline = None
+    if not args.no_roofline and rank == 0:
+        # dominant kernel = conv_gemm_kernel (denoiser forward + input-VJP): per-launch HIP events on
+        # the launch stream over a short profiled stretch of the same workload
+        L = _cabi.lib()
+        n_prof_steps = 5
+        _cabi.check(L.trace_profile_begin(200 * n_prof_steps), "trace_profile_begin")
+        model.sampler(batch, N, class_free_guide_w=wl["w"], guide_clean=wl["clean"], n_steps=n_prof_steps,
+                      generator=gen)
+        ms, nl, fl = C.c_double(), C.c_int64(), C.c_double()
+        _cabi.check(L.trace_profile_end(C.byref(ms), C.byref(nl), C.byref(fl)), "trace_profile_end")
+        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+        peak = 157.3
+        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)",
+                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "traffic": None, "launches": int(nl.value),
+                    "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
+                    "conv_ms_per_ddpm_step": ms.value / n_prof_steps}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        total = M * world * args.steps
+        res = {
+            "metric": "guided trajectory samples/sec (100 DDPM steps, 52-step horizon)",
+            "value": total / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic (seeded ORCA-style scenes, random-init orca_mixed weights)",
+            "config": {"workload": args.workload, "agents_per_gpu": B, "samples_per_agent": N,
+                       "trajectories_per_gpu": M, "ddpm_steps": cfg.n_diffusion_steps,
+                       "horizon": cfg.horizon, "class_free_guide_w": wl["w"],
+                       "guidance": wl["guide"], "guide_clean": wl["clean"],
+                       "parallelism": "scenes sharded over %d GPU(s), all-gather of scores/plans" % world},
+        }
+        if roofline is not None:
+            res["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, args.workload)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,15 @@ int trace_unet_forward(trace_unet* u, const float* x_in, const float* cond_table
 int trace_unet_backward_input(trace_unet* u, const float* grad_pred, int rows, float* grad_x,
                               void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Per-launch timing of the implicit-GEMM conv kernels (the dominant kernel): between begin and
+ * end every conv launch is bracketed by HIP events on its stream.  end() synchronises on the
+ * events and returns the summed kernel time, the number of launches and their algorithmic FLOPs
+ * (2 * rows * L_out * C_out * C_in * taps, structural zeros of transposed convs not counted).
+ * No counterpart in the reference (it has no profiling hooks); used by
+ * bench.py for the roofline figures. */
+int trace_profile_begin(int max_launches);
+int trace_profile_end(double* total_ms, int64_t* launches, double* total_flops);
+
 /* ------------------------------------------------------------- sampler steps ---- */
 /* Constants of the sampler: normalisation (tbsim/models/trace.py:415-447), unicycle bounds
  * (tbsim/dynamics/unicycle.py:7-18), dt. */

@@ -6,6 +6,12 @@ importing/using the product path raises.  Build it with ``python -m trace_amd.bu
 import ctypes as C
 import os
 
+# torch bundles its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as /opt/rocm's).  It
+# must be loaded BEFORE libtrace_hip.so so that both share ONE runtime instance (streams and
+# device pointers cross the boundary); the other order leaves two runtimes in the process and
+# the second one reports "no ROCm-capable device".
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtrace_hip.so")
 
@@ -53,6 +59,8 @@ PROTOTYPES = {
     "trace_unet_workspace_bytes": (_L, [_P, _I, _I]),
     "trace_unet_forward": (_I, [_P, _P, _P, _I, _I, _I, _P, _P, _L, _I, _P]),
     "trace_unet_backward_input": (_I, [_P, _P, _I, _P, _P, _L, _P]),
+    "trace_profile_begin": (_I, [_I]),
+    "trace_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double)]),
     "trace_map_query": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F,
                              C.POINTER(DynParams), _P]),
     "trace_dyn_rollout": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(DynParams), _P]),

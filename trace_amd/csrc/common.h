@@ -28,6 +28,12 @@ void set_error(const char* fmt, ...);
     }                                     \
   } while (0)
 
+// Optional per-launch timing of the conv kernels (bench.py roofline): HIP events recorded on
+// the launch stream around every conv_gemm launch while a profile is open.
+bool prof_active();
+void prof_pre(hipStream_t st);
+void prof_post(hipStream_t st, double flops);
+
 inline int launch_status(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -5,13 +5,17 @@
 //   rows   = (trajectory, output position) flattened; a workgroup owns TB whole trajectories
 //            (TB*L_OUT = 208 rows = 13 MFMA row tiles) so GroupNorm statistics never leave it
 //   cols   = 64 output channels per workgroup (4 waves x one 16-wide MFMA column tile)
-//   K      = taps x input channels, streamed in chunks of <=64 channels through LDS
+//   K      = taps x input channels, streamed in chunks of CH (<=64) channels through LDS
 //
 // A operand: activations staged once per chunk into LDS, channel-major with zeroed halo /
-//            zero-stuffing, read with ds_read_b32 (lanes = consecutive positions: conflict-free)
+//            zero-stuffing, read with ds_read_b32 (lanes = consecutive positions: conflict-free),
+//            software-pipelined one k-step (13 reads) ahead of the MFMAs that consume them
 // B operand: weights pre-packed on the host in MFMA fragment order, streamed L2 -> VGPR with one
 //            coalesced dwordx4 per 16 k (no LDS, no barrier in the K loop), prefetched one
 //            k-block ahead
+// staging  : the next chunk's activations are fetched global -> VGPR (dwordx4) before the K loop
+//            of the current chunk and written to LDS after it (issue early / write late), so HBM
+//            / L2 latency hides under the MFMAs
 #pragma once
 #include "common.h"
 
@@ -21,10 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
   const float* in;     // [rows][in_ctot][L_IN]
-  int in_tstride;      // floats per trajectory
-  int in_coff;         // first input channel
+  int in_tstride;      // floats per trajectory (multiple of 4)
+  int in_coff;         // first input channel (multiple of 16)
   int cin;             // input channels (multiple of chunk)
-  int chunk;           // channels per LDS stage (multiple of 16)
+  int chunk;           // channels per LDS stage (selects the template instance)
   const f32x4* wp;     // packed weights [cout/16][nkb][64]
   int nkb;             // k-blocks (16 k each) = taps * cin / 16
   const float* bias;   // [cout] or null
@@ -35,7 +39,7 @@ struct ConvArgs {
   int rows;
   // epilogue
   int gn;              // GroupNorm + Mish
-  int cg;              // channels per group
+  int cg;              // channels per group (power of two)
   const float* gamma;
   const float* beta;
   float* ysave;        // pre-norm conv output [rows][cout][L_OUT] (input-VJP) or null
@@ -51,9 +55,10 @@ struct ConvArgs {
   const float* res2;
   int res2_tstride;
   int res2_coff;
+  double alg_macs_per_pos;   // algorithmic MACs per (row, output position): cout * cin_real * taps_alg
 };
 
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB>
+template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
 struct ConvGeom {
   static constexpr int R = TB * L_OUT;
   static constexpr int NRT = R / 16;
@@ -61,17 +66,22 @@ struct ConvGeom {
   static constexpr int S = TB * LP;
   static constexpr int L_IN = (L_OUT * IN_STRIDE) / UP;
   static constexpr int RS = R + 4;
+  static constexpr int F4_PER_TRAJ = CH * L_IN / 4;        // float4 per trajectory per chunk
+  static constexpr int F4_TOTAL = TB * F4_PER_TRAJ;
+  static constexpr int NF4 = (F4_TOTAL + 255) / 256;       // staging registers (float4) per thread
+  static constexpr int KBPC = CH / 16;
+  static constexpr int NKK = TAPS * KBPC;
   static_assert(R % 16 == 0, "row block must be a whole number of MFMA tiles");
-  static size_t lds_floats(int chunk) {
-    size_t a = (size_t)chunk * S, b = (size_t)64 * RS + 2 * TB * 8;
-    return a > b ? a : b;
-  }
+  static_assert((CH * L_IN) % 4 == 0 && CH % 16 == 0, "chunk must be float4 / k-block aligned");
+  static constexpr size_t LDS_FLOATS =
+      ((size_t)CH * S > (size_t)64 * RS + 2 * TB * 8) ? (size_t)CH * S : (size_t)64 * RS + 2 * TB * 8;
 };
 
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB>
+template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
-  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB>;
+  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
   constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, RS = G::RS;
+  constexpr int NF4 = G::NF4, KBPC = G::KBPC, NKK = G::NKK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
   const int tid = threadIdx.x;
@@ -80,7 +90,54 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   const int traj0 = blockIdx.x * TB;
   const int co0 = blockIdx.y * 64;
 
-  for (int i = tid; i < a.chunk * S; i += 256) lds[i] = 0.f;
+  // ---- staging: thread handles float4 #(tid + 256 j) of the chunk -------------------------
+  // Buffer loads with a 32-bit byte offset: the descriptor's range check returns 0 for
+  // trajectories past `rows` (tail workgroup), so there is no per-load predicate.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
+      0x00020000);
+  unsigned soff[NF4];
+#pragma unroll
+  for (int j = 0; j < NF4; ++j) {
+    const int q = tid + 256 * j;
+    const int tr = q / G::F4_PER_TRAJ;
+    const int rem = q - tr * G::F4_PER_TRAJ;
+    soff[j] = q < G::F4_TOTAL
+                  ? (unsigned)(((traj0 + tr) * a.in_tstride + a.in_coff * L_IN + rem * 4) * 4)
+                  : 0xffffffffu;     // out of range -> zeros
+  }
+  f32x4 stg[NF4];
+  auto stage_load = [&](int c0) {
+    const unsigned cb = (unsigned)(c0 * L_IN * 4);
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, soff[j] == 0xffffffffu ? soff[j] : soff[j] + cb,
+                                                     0, 0);
+      stg[j] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int q = tid + 256 * j;
+      if (q < G::F4_TOTAL) {
+        const int tr = q / G::F4_PER_TRAJ;
+        const int e0 = (q - tr * G::F4_PER_TRAJ) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u;
+          const int ci = e / L_IN;
+          const int i = e - ci * L_IN;
+          lds[ci * S + tr * LP + i * UP + PADL] = stg[j][u];
+        }
+      }
+    }
+  };
+
+  stage_load(0);
+  // halo / zero-stuffing positions are written once; data positions are the same for every chunk
+#pragma unroll 2
+  for (int i = tid; i < CH * S; i += 256) lds[i] = 0.f;
 
   int rowoff[NRT];
 #pragma unroll
@@ -95,43 +152,55 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const f32x4* wp = a.wp + ((size_t)(blockIdx.y * 4 + wave) * a.nkb) * 64 + lane;
-  const int kbpc = a.chunk >> 4;
-  const int nkk = TAPS * kbpc;
   f32x4 bnext = *wp;
   int kdone = 0;
 
-  for (int c0 = 0; c0 < a.cin; c0 += a.chunk) {
+  for (int c0 = 0; c0 < a.cin; c0 += CH) {
+    __syncthreads();            // previous chunk fully consumed (and zero fill done)
+    stage_write();
+    if (c0 + CH < a.cin) stage_load(c0 + CH);   // in flight during this chunk's K loop
     __syncthreads();
-    {
-      const int n_el = a.chunk * L_IN;
-      for (int idx = tid; idx < TB * n_el; idx += 256) {
-        int tr = idx / n_el;
-        int rem = idx - tr * n_el;
-        int ci = rem / L_IN;
-        int i = rem - ci * L_IN;
-        int tg = traj0 + tr;
-        if (tg < a.rows)
-          lds[ci * S + tr * LP + i * UP + PADL] =
-              a.in[(size_t)tg * a.in_tstride + (size_t)(a.in_coff + c0 + ci) * L_IN + i];
-      }
-    }
-    __syncthreads();
+
+    float a0[NRT], a1[NRT];
+    const float* lp = lds;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) a0[rt] = lp[rowoff[rt]];
     int tap = 0, kb = 0;
-    for (int kk = 0; kk < nkk; ++kk) {
-      f32x4 b = bnext;
+    for (int kk = 0; kk < NKK; ++kk) {
+      const f32x4 b = bnext;
       ++kdone;
       wp += 64;
       if (kdone < a.nkb) bnext = *wp;
-      const float* lp = lds + kb * 16 * S + tap;
+      int kb2 = kb + 1, tap2 = tap;
+      if (kb2 == KBPC) { kb2 = 0; ++tap2; }
+      const float* lpn = lds + kb2 * 16 * S + tap2;
+      const bool more = kk + 1 < NKK;
+      // 4 k-steps; A values for step s+1 are read while step s multiplies
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int rt = 0; rt < NRT; ++rt) a1[rt] = lp[rowoff[rt] + 4 * S];
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) {
-          float av = lp[rowoff[rt] + s * 4 * S];
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[s], acc[rt], 0, 0, 0);
-        }
+      for (int rt = 0; rt < NRT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], b[0], acc[rt], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) a0[rt] = lp[rowoff[rt] + 8 * S];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], b[1], acc[rt], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) a1[rt] = lp[rowoff[rt] + 12 * S];
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], b[2], acc[rt], 0, 0, 0);
+      if (more) {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt) a0[rt] = lpn[rowoff[rt]];
       }
-      if (++kb == kbpc) { kb = 0; ++tap; }
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], b[3], acc[rt], 0, 0, 0);
+      lp = lpn;
+      kb = kb2;
+      tap = tap2;
     }
   }
 
@@ -150,7 +219,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   }
   __syncthreads();
   float* stat = lds + 64 * RS;
-  const int gps = a.gn ? 64 / a.cg : 1;
+  const int cg_shift = a.gn ? __builtin_ctz(a.cg) : 0;
+  const int gps = a.gn ? (64 >> cg_shift) : 1;
   if (a.gn) {
     const int nunits = TB * gps;
     const int n = a.cg * L_OUT;
@@ -180,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
         stat[2 * u + 1] = rstd;
         int tg = traj0 + tr;
         if (a.stats && tg < a.rows) {
-          size_t si = ((size_t)tg * (a.cout / a.cg) + (co0 / a.cg + g)) * 2;
+          size_t si = ((size_t)tg * (a.cout >> cg_shift) + ((co0 >> cg_shift) + g)) * 2;
           a.stats[si] = mean;
           a.stats[si + 1] = rstd;
         }
@@ -194,47 +264,62 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     if (tg >= a.rows) break;
     const float* pcrow =
         a.pc ? a.pc + (size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co0 : nullptr;
+    const float* resp =
+        a.res ? a.res + (size_t)tg * a.res_tstride + (size_t)(a.res_coff + co0) * L_OUT : nullptr;
+    const float* res2p =
+        a.res2 ? a.res2 + (size_t)tg * a.res2_tstride + (size_t)(a.res2_coff + co0) * L_OUT : nullptr;
+    float* outp = a.out + (size_t)tg * a.out_tstride + (size_t)(a.out_coff + co0) * L_OUT;
+    float* ysp = a.ysave ? a.ysave + ((size_t)tg * a.cout + co0) * L_OUT : nullptr;
     for (int e = tid; e < 64 * L_OUT; e += 256) {
       int c = e / L_OUT;
       int l = e - c * L_OUT;
       int co = co0 + c;
       float y = lds[c * RS + tr * L_OUT + l];
-      if (a.ysave) a.ysave[((size_t)tg * a.cout + co) * L_OUT + l] = y;
+      if (ysp) ysp[e] = y;
       if (a.gn) {
-        int u = tr * gps + c / a.cg;
+        int u = tr * gps + (c >> cg_shift);
         float z = (y - stat[2 * u]) * stat[2 * u + 1] * a.gamma[co] + a.beta[co];
         y = mish_f(z);
       }
       if (pcrow) y += pcrow[c] + a.pt[co];
-      if (a.res) y += a.res[(size_t)tg * a.res_tstride + (size_t)(a.res_coff + co) * L_OUT + l];
-      if (a.res2) y += a.res2[(size_t)tg * a.res2_tstride + (size_t)(a.res2_coff + co) * L_OUT + l];
-      a.out[(size_t)tg * a.out_tstride + (size_t)(a.out_coff + co) * L_OUT + l] = y;
+      if (resp) y += resp[e];
+      if (res2p) y += res2p[e];
+      outp[e] = y;
     }
   }
 }
 
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB>
+template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
 int launch_conv(const ConvArgs& a, hipStream_t st) {
-  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB>;
+  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
   if (a.rows <= 0) return TRACE_OK;
-  TRACE_REQUIRE(a.cout % 64 == 0 && a.chunk % 16 == 0 && a.cin % a.chunk == 0 &&
-                    a.nkb == TAPS * a.cin / 16,
-                "conv: bad channel geometry cin=%d chunk=%d cout=%d nkb=%d", a.cin, a.chunk,
-                a.cout, a.nkb);
-  TRACE_REQUIRE(!a.gn || (a.cg > 0 && 64 % a.cg == 0), "conv: group size %d", a.cg);
-  size_t lds_bytes = G::lds_floats(a.chunk) * sizeof(float);
+  TRACE_REQUIRE(a.cout % 64 == 0 && a.chunk == CH && a.cin % CH == 0 && a.nkb == TAPS * a.cin / 16,
+                "conv: bad channel geometry cin=%d chunk=%d cout=%d nkb=%d", a.cin, a.chunk, a.cout,
+                a.nkb);
+  TRACE_REQUIRE(!a.gn || (a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64), "conv: group size %d",
+                a.cg);
+  TRACE_REQUIRE(a.in_tstride % 4 == 0 && a.in_coff % 16 == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.in) & 15) == 0,
+                "conv: input must be 16-byte aligned per trajectory chunk");
+  TRACE_REQUIRE((size_t)a.rows * a.in_tstride * sizeof(float) < 0xffffffffull,
+                "conv: input of %d rows exceeds the 4 GiB buffer-descriptor range; split the rows",
+                a.rows);
+  constexpr size_t lds_bytes = G::LDS_FLOATS * sizeof(float);
   // two workgroups per CU must fit in the 160 KiB LDS
-  TRACE_REQUIRE(lds_bytes <= 80 * 1024, "conv: LDS %zu too large", lds_bytes);
+  static_assert(lds_bytes <= 80 * 1024, "conv: LDS per workgroup too large");
   static bool attr_set = false;
   if (!attr_set) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB>),
+        reinterpret_cast<const void*>(&conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr_set = true;
   }
   dim3 grid((a.rows + TB - 1) / TB, a.cout / 64);
-  hipLaunchKernelGGL((conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB>), grid, dim3(256),
+  const bool prof = prof_active();
+  if (prof) prof_pre(st);
+  hipLaunchKernelGGL((conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>), grid, dim3(256),
                      lds_bytes, st, a);
+  if (prof) prof_post(st, 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT);
   return launch_status("conv_gemm_kernel");
 }
 

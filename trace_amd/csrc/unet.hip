@@ -18,6 +18,27 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// ---- per-launch conv timing (see trace_profile_begin / trace_profile_end) ----------------
+namespace {
+struct Prof {
+  bool on = false;
+  int n = 0;
+  std::vector<hipEvent_t> ev;   // 2 per launch
+  std::vector<double> flops;
+} g_prof;
+}  // namespace
+bool prof_active() { return g_prof.on; }
+void prof_pre(hipStream_t st) {
+  if (g_prof.n * 2 + 1 >= (int)g_prof.ev.size()) { g_prof.on = false; return; }
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
+}
+void prof_post(hipStream_t st, double flops) {
+  if (!g_prof.on) return;
+  (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
+  g_prof.flops[g_prof.n] = flops;
+  ++g_prof.n;
+}
+
 // --------------------------------------------------------------------------------------
 // small kernels
 // --------------------------------------------------------------------------------------
@@ -162,6 +183,7 @@ namespace {
 struct PackedConv {
   f32x4* w = nullptr;  // device, [cout/16][nkb][64]
   int cin = 0;         // padded
+  int cin_real = 0;
   int cout = 0;
   int taps = 0;
   int chunk = 0;
@@ -257,6 +279,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
   if (rc) return rc;
   pc->w = reinterpret_cast<f32x4*>(d);
   pc->cin = cin;
+  pc->cin_real = cin_real;
   pc->cout = cout;
   pc->taps = taps;
   pc->chunk = chunk;
@@ -594,36 +617,42 @@ Layout make_layout(const trace_unet* u, int rows, int save) {
 
 enum ConvKind { K_CONV5, K_CONV1, K_DOWN_F, K_UP_F, K_DOWN_B, K_UP_B };
 
-int run_conv(ConvKind kind, int L_out, const ConvArgs& a, hipStream_t st) {
+int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
+  ConvArgs a = a_in;
+  // zero-stuffed (transposed) convolutions multiply half of their taps by structural zeros
+  if (kind == K_UP_F || kind == K_DOWN_B) a.alg_macs_per_pos *= 0.5;
+  const int ch = a.chunk;
   switch (kind) {
     case K_CONV5:
-      if (L_out == 52) return launch_conv<52, 1, 1, 5, 2, 4>(a, st);
-      if (L_out == 26) return launch_conv<26, 1, 1, 5, 2, 8>(a, st);
-      if (L_out == 13) return launch_conv<13, 1, 1, 5, 2, 16>(a, st);
+      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 1, 5, 2, 4, 64>(a, st);
+      if (L_out == 52 && ch == 48) return launch_conv<52, 1, 1, 5, 2, 4, 48>(a, st);
+      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 1, 5, 2, 8, 64>(a, st);
+      if (L_out == 13 && ch == 64) return launch_conv<13, 1, 1, 5, 2, 16, 64>(a, st);
       break;
     case K_CONV1:
-      if (L_out == 52) return launch_conv<52, 1, 1, 1, 0, 4>(a, st);
-      if (L_out == 26) return launch_conv<26, 1, 1, 1, 0, 8>(a, st);
-      if (L_out == 13) return launch_conv<13, 1, 1, 1, 0, 16>(a, st);
+      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 1, 1, 0, 4, 64>(a, st);
+      if (L_out == 52 && ch == 48) return launch_conv<52, 1, 1, 1, 0, 4, 48>(a, st);
+      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 1, 1, 0, 8, 64>(a, st);
+      if (L_out == 13 && ch == 64) return launch_conv<13, 1, 1, 1, 0, 16, 64>(a, st);
       break;
     case K_DOWN_F:
-      if (L_out == 26) return launch_conv<26, 2, 1, 3, 1, 8>(a, st);
-      if (L_out == 13) return launch_conv<13, 2, 1, 3, 1, 16>(a, st);
+      if (L_out == 26 && ch == 32) return launch_conv<26, 2, 1, 3, 1, 8, 32>(a, st);
+      if (L_out == 13 && ch == 32) return launch_conv<13, 2, 1, 3, 1, 16, 32>(a, st);
       break;
     case K_UP_F:
-      if (L_out == 26) return launch_conv<26, 1, 2, 4, 2, 8>(a, st);
-      if (L_out == 52) return launch_conv<52, 1, 2, 4, 2, 4>(a, st);
+      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 2, 4, 2, 8, 64>(a, st);
+      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 2, 4, 2, 4, 64>(a, st);
       break;
     case K_DOWN_B:
-      if (L_out == 52) return launch_conv<52, 1, 2, 3, 1, 4>(a, st);
-      if (L_out == 26) return launch_conv<26, 1, 2, 3, 1, 8>(a, st);
+      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 2, 3, 1, 4, 64>(a, st);
+      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 2, 3, 1, 8, 64>(a, st);
       break;
     case K_UP_B:
-      if (L_out == 13) return launch_conv<13, 2, 1, 4, 1, 16>(a, st);
-      if (L_out == 26) return launch_conv<26, 2, 1, 4, 1, 8>(a, st);
+      if (L_out == 13 && ch == 32) return launch_conv<13, 2, 1, 4, 1, 16, 32>(a, st);
+      if (L_out == 26 && ch == 32) return launch_conv<26, 2, 1, 4, 1, 8, 32>(a, st);
       break;
   }
-  set_error("no conv kernel for kind %d L_out %d", (int)kind, L_out);
+  set_error("no conv kernel for kind %d L_out %d chunk %d", (int)kind, L_out, ch);
   return TRACE_EINVAL;
 }
 
@@ -651,6 +680,7 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.out_coff = out.coff;
   a.cout = w.cout;
   a.rows = rows;
+  a.alg_macs_per_pos = (double)w.cout * w.cin_real * w.taps;
   return a;
 }
 
@@ -888,5 +918,37 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
                        u->first_wsel, u->first_rsel, grad_x, d0, H, rows);
     RUN(launch_status("first_dgrad_kernel"));
   }
+  return TRACE_OK;
+}
+
+// ---- profiling entry points ---------------------------------------------------------------
+extern "C" int trace_profile_begin(int max_launches) {
+  TRACE_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), "trace_profile_begin: bad size");
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.assign((size_t)max_launches * 2, nullptr);
+  g_prof.flops.assign(max_launches, 0.0);
+  for (auto& e : g_prof.ev) TRACE_CHECK_HIP(hipEventCreate(&e));
+  g_prof.n = 0;
+  g_prof.on = true;
+  return TRACE_OK;
+}
+
+extern "C" int trace_profile_end(double* total_ms, int64_t* launches, double* total_flops) {
+  TRACE_REQUIRE(total_ms && launches && total_flops, "trace_profile_end: null argument");
+  g_prof.on = false;
+  double ms = 0.0, fl = 0.0;
+  for (int i = 0; i < g_prof.n; ++i) {
+    TRACE_CHECK_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+    float t = 0.f;
+    TRACE_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+    ms += t;
+    fl += g_prof.flops[i];
+  }
+  *total_ms = ms;
+  *launches = g_prof.n;
+  *total_flops = fl;
+  for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.n = 0;
   return TRACE_OK;
 }

@@ -353,14 +353,20 @@ class GuidancePlan:
     def guide_losses(self, layer_losses):
         return GuideLosses(self, layer_losses)
 
+    def total_scores(self, layer_losses):
+        """(B, N) unweighted sum of all guidance losses covering each agent."""
+        B, N, dev = self.B, self.N, self.device
+        total = torch.zeros(B, N, device=dev)
+        for ly, l in zip(self.layers, layer_losses):
+            total += l.view(B, N) * ly["mask"].to(dev).unsqueeze(1)
+        return total
+
     def choose_action(self, layer_losses):
         """choose_action_from_guidance (guidance_loss.py:15-41), on device and without the
         per-guide NaN-padded tensors: unweighted sum of the guides per agent; per-agent argmin,
         or one argmin per scene when the scene has a scene-level guide."""
         B, N, dev = self.B, self.N, self.device
-        total = torch.zeros(B, N, device=dev)
-        for ly, l in zip(self.layers, layer_losses):
-            total += l.view(B, N) * ly["mask"].to(dev).unsqueeze(1)
+        total = self.total_scores(layer_losses)
         idx = torch.zeros(B, dtype=torch.long, device=dev)
         valid = self.sel_valid
         per_agent = torch.argmin(total, dim=-1)

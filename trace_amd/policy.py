@@ -1,0 +1,288 @@
+"""Policy boundary of the sampler: the objects the reference's evaluation driver talks to.
+
+Mirrors (same names, argument meaning and return structure):
+  * ``Action`` / ``RolloutAction``      -- /root/reference/tbsim/policies/common.py:8-64,107-180
+  * ``PolicyWrapper`` / ``RolloutWrapper`` -- /root/reference/tbsim/policies/wrappers.py:6-65
+  * ``DiffuserTrafficModel.get_action / set_guidance / clear_guidance``
+                                          -- /root/reference/tbsim/algos/algos.py:261-326
+  * ``Diffuser`` composer               -- /root/reference/tbsim/evaluation/policy_composers.py:27-57
+
+The ``tbsim/`` package at the repo root re-exports these under the reference's import paths
+(``tbsim.evaluation.policy_composers.Diffuser`` ...), which is how
+``scripts/scene_editor.py --eval_class Diffuser`` resolves them (scene_editor.py:48-51).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from .config import ModelConfig
+from .sampler import TraceSampler
+from .weights import extract_policy_state_dict, random_state_dict
+
+
+def _clone(x):
+    return x.clone() if torch.is_tensor(x) else np.array(x, copy=True)
+
+
+def _to_numpy(x):
+    if isinstance(x, dict):
+        return {k: _to_numpy(v) for k, v in x.items()}
+    if torch.is_tensor(x):
+        return x.detach().cpu().numpy()
+    return x
+
+
+class Action(object):
+    """Positions (…,T,2) and yaws (…,T,1) of the chosen plan."""
+
+    def __init__(self, positions, yaws):
+        assert positions.shape[:-1] == yaws.shape[:-1]
+        assert positions.shape[-1] == 2 and yaws.shape[-1] == 1
+        self._positions, self._yaws = positions, yaws
+
+    @property
+    def positions(self):
+        return _clone(self._positions)
+
+    @property
+    def yaws(self):
+        return _clone(self._yaws)
+
+    @property
+    def trajectories(self):
+        if isinstance(self._positions, np.ndarray):
+            return np.concatenate([self._positions, self._yaws], axis=-1)
+        return torch.cat([self._positions, self._yaws], dim=-1)
+
+    def to_dict(self):
+        return dict(positions=self.positions, yaws=self.yaws)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**d)
+
+    def to_numpy(self):
+        return self.__class__(**_to_numpy(self.to_dict()))
+
+
+class RolloutAction(object):
+    def __init__(self, ego=None, ego_info=None, agents=None, agents_info=None):
+        assert ego is None or isinstance(ego, Action)
+        assert agents is None or isinstance(agents, Action)
+        self.ego, self.ego_info, self.agents, self.agents_info = ego, ego_info, agents, agents_info
+
+    @property
+    def has_ego(self):
+        return self.ego is not None
+
+    @property
+    def has_agents(self):
+        return self.agents is not None
+
+    def to_numpy(self):
+        return self.__class__(
+            ego=self.ego.to_numpy() if self.has_ego else None,
+            ego_info=_to_numpy(self.ego_info) if self.has_ego else None,
+            agents=self.agents.to_numpy() if self.has_agents else None,
+            agents_info=_to_numpy(self.agents_info) if self.has_agents else None)
+
+
+class PolicyWrapper(object):
+    """Binds run-time keyword arguments of ``get_action`` (wrappers.py:6-30)."""
+
+    def __init__(self, model, get_action_kwargs=None, get_plan_kwargs=None):
+        self.model = model
+        self.device = model.device
+        self.action_kwargs = get_action_kwargs or {}
+        self.plan_kwargs = get_plan_kwargs
+
+    def eval(self):
+        self.model.eval()
+
+    def get_action(self, obs, **kwargs):
+        return self.model.get_action(obs, **self.action_kwargs, **kwargs)
+
+    @classmethod
+    def wrap_controller(cls, model, **kwargs):
+        return cls(model=model, get_action_kwargs=kwargs)
+
+
+class RolloutWrapper(object):
+    """wrappers.py:33-65 (agents policy only is the path TRACE uses)."""
+
+    def __init__(self, ego_policy=None, agents_policy=None, pass_agent_obs=True):
+        self.device = ego_policy.device if agents_policy is None else agents_policy.device
+        self.ego_policy, self.agents_policy, self.pass_agent_obs = ego_policy, agents_policy, pass_agent_obs
+
+    def eval(self):
+        for p in (self.ego_policy, self.agents_policy):
+            if p is not None:
+                p.eval()
+
+    def get_action(self, obs, step_index):
+        ego = ego_info = agents = agents_info = None
+        with torch.no_grad():
+            if self.ego_policy is not None:
+                assert obs["ego"] is not None
+                kw = dict(agent_obs=obs["agents"]) if self.pass_agent_obs else {}
+                ego, ego_info = self.ego_policy.get_action(obs["ego"], step_index=step_index, **kw)
+            if self.agents_policy is not None:
+                assert obs["agents"] is not None
+                agents, agents_info = self.agents_policy.get_action(obs["agents"], step_index=step_index)
+        return RolloutAction(ego, ego_info, agents, agents_info)
+
+
+def choose_action_from_gt(preds, obs_dict):
+    """Sample closest to the ground-truth future (guidance_loss.py:43-65)."""
+    B, N, T, _ = preds["positions"].shape
+    idx = torch.zeros(B, dtype=torch.long, device=preds["positions"].device)
+    if "target_positions" not in obs_dict:
+        return idx
+    end = min(T, obs_dict["target_positions"].shape[1])
+    gt = obs_dict["target_positions"][:, :end].unsqueeze(1).to(preds["positions"].device)
+    valid = obs_dict["target_availabilities"][:, :end].unsqueeze(1).expand(B, N, end).to(gt.device)
+    err = torch.norm(preds["positions"][:, :, :end] - gt, dim=-1)
+    err = torch.where(valid.bool(), err, torch.full_like(err, float("nan")))
+    ade = torch.nanmean(err, dim=-1)
+    ok = torch.isnan(ade).sum(dim=-1) == 0
+    best = torch.argmin(torch.nan_to_num(ade, nan=float("inf")), dim=-1)
+    return torch.where(ok, best, idx)
+
+
+class DiffuserTrafficModel(object):
+    """Algo-level object with the reference's inference interface (algos.py:19-326).  Holds one
+    ``TraceSampler`` (the EMA copy is what inference uses, algos.py:268-271)."""
+
+    def __init__(self, model_config: ModelConfig, state_dict, device="cuda:0", guidance_config=None,
+                 map_encoder=None):
+        self.algo_config = model_config
+        self.device = torch.device(device)
+        self.sampler = TraceSampler(model_config, state_dict, device, map_encoder=map_encoder)
+        if guidance_config is not None:
+            self.set_guidance(guidance_config)
+
+    @classmethod
+    def load_from_checkpoint(cls, ckpt_path, model_config, device="cuda:0", use_ema=True, **kw):
+        """Loads a Lightning ``.ckpt`` written by the reference's training.
+        Only tensors are read (``weights_only=True``)."""
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=True)
+        sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        return cls(model_config, extract_policy_state_dict(sd, use_ema), device, **kw)
+
+    def eval(self):
+        return self
+
+    def to(self, device):
+        assert torch.device(device) == self.device, "construct the model on its target device"
+        return self
+
+    def set_guidance(self, guidance_config, example_batch=None):
+        self.sampler.set_guidance(guidance_config, example_batch)
+
+    def clear_guidance(self):
+        self.sampler.clear_guidance()
+
+    def forward(self, obs_dict, num_samp=1, class_free_guide_w=0.0, guide_as_filter_only=False,
+                guide_clean=False, **sampler_kwargs):
+        return self.sampler(obs_dict, num_samp, return_diffusion=True, return_guidance_losses=True,
+                            class_free_guide_w=class_free_guide_w,
+                            apply_guidance=(not guide_as_filter_only), guide_clean=guide_clean,
+                            **sampler_kwargs)
+
+    __call__ = forward
+
+    def get_action(self, obs_dict, num_action_samples=1, class_free_guide_w=0.0,
+                   guide_as_filter_only=False, guide_with_gt=False, guide_clean=False, **kwargs):
+        step_index = kwargs.pop("step_index")
+        self.sampler.update_guidance(global_t=step_index)
+        sampler_kwargs = {k: kwargs[k] for k in ("noise_init", "noise_steps", "generator") if k in kwargs}
+        out = self.forward(obs_dict, num_samp=num_action_samples, class_free_guide_w=class_free_guide_w,
+                           guide_as_filter_only=guide_as_filter_only, guide_clean=guide_clean,
+                           **sampler_kwargs)
+        preds = out["predictions"]
+        B = preds["positions"].shape[0]
+        act_idx = torch.zeros(B, dtype=torch.long, device=preds["positions"].device)
+        if guide_with_gt and "target_positions" in obs_dict:
+            act_idx = choose_action_from_gt(preds, obs_dict)
+        guide_scores = None
+        if self.sampler.current_guidance is not None:
+            guide_scores = out["guidance_plan"].total_scores(out["guidance_layer_losses"])
+        if guide_with_gt and "target_positions" in obs_dict:
+            pass
+        elif self.sampler.current_guidance is not None:
+            act_idx = out["guidance_plan"].choose_action(out["guidance_layer_losses"])
+        ar = torch.arange(B, device=act_idx.device)
+        info = dict(
+            action_samples=Action(positions=preds["positions"], yaws=preds["yaws"]).to_dict(),
+            diffusion_steps={"traj": preds["diffusion_steps"][ar, act_idx]},
+            act_idx=act_idx,
+        )
+        if "guide_losses" in preds:
+            info["guide_losses"] = preds["guide_losses"]
+        if guide_scores is not None:
+            info["guide_scores"] = guide_scores
+        action = Action(positions=preds["positions"][ar, act_idx], yaws=preds["yaws"][ar, act_idx])
+        return action, info
+
+
+class Diffuser(object):
+    """Policy composer selected by ``eval_cfg.eval_class`` (policy_composers.py:27-57).
+    ``eval_config`` needs ``.policy.{num_action_samples, class_free_guide_w, guide_as_filter_only,
+    guide_with_gt, guide_clean}`` and ``.ckpt.policy.{ckpt_dir, ckpt_key}`` (attribute or dict
+    access).  Without a checkpoint on disk (none ship with the reference) it falls back to
+    seeded random weights of the orca_mixed architecture when ``allow_random_init`` is set."""
+
+    def __init__(self, eval_config, device, ckpt_root_dir="checkpoints/", allow_random_init=False,
+                 seed=0):
+        self.eval_config, self.device, self.ckpt_root_dir = eval_config, device, ckpt_root_dir
+        self.allow_random_init, self.seed = allow_random_init, seed
+
+    @staticmethod
+    def _get(cfg, *path):
+        for p in path:
+            cfg = cfg[p] if isinstance(cfg, dict) else getattr(cfg, p)
+        return cfg
+
+    def _find_checkpoint(self):
+        try:
+            ckpt_dir = self._get(self.eval_config, "ckpt", "policy", "ckpt_dir")
+            ckpt_key = self._get(self.eval_config, "ckpt", "policy", "ckpt_key")
+        except (KeyError, AttributeError):
+            return None, None
+        root = os.path.join(self.ckpt_root_dir, ckpt_dir) if ckpt_dir else None
+        if not root or not os.path.isdir(root):
+            return None, None
+        ckpt = cfg = None
+        for dirpath, _, files in os.walk(root):
+            for f in files:
+                if f.endswith(".ckpt") and ckpt_key in f:
+                    ckpt = os.path.join(dirpath, f)
+                if f == "config.json":
+                    cfg = os.path.join(dirpath, f)
+        return ckpt, cfg
+
+    def get_policy(self, policy=None):
+        policy_cfg = None
+        if policy is None:
+            ckpt, cfg_path = self._find_checkpoint()
+            if ckpt is not None and cfg_path is not None:
+                with open(cfg_path) as f:
+                    policy_cfg = json.load(f)
+                mc = ModelConfig.from_algo_dict(policy_cfg["algo"])
+                policy = DiffuserTrafficModel.load_from_checkpoint(ckpt, mc, self.device)
+            elif self.allow_random_init:
+                mc = ModelConfig()
+                policy = DiffuserTrafficModel(mc, random_state_dict(mc, self.seed), self.device)
+                policy_cfg = {"algo": mc.to_algo_dict()}
+            else:
+                raise FileNotFoundError("no TRACE checkpoint found under %s" % self.ckpt_root_dir)
+        pc = self._get(self.eval_config, "policy")
+        g = (lambda k: pc[k]) if isinstance(pc, dict) else (lambda k: getattr(pc, k))
+        wrapped = PolicyWrapper.wrap_controller(
+            policy, num_action_samples=g("num_action_samples"),
+            class_free_guide_w=g("class_free_guide_w"),
+            guide_as_filter_only=g("guide_as_filter_only"), guide_with_gt=g("guide_with_gt"),
+            guide_clean=g("guide_clean"))
+        return wrapped, policy_cfg
