@@ -1,0 +1,24 @@
+"""Runs a few denoiser forward (+ input-VJP) passes at bench shape, for rocprofv3 counter passes."""
+import os, sys, ctypes as C, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from trace_amd import _cabi
+from trace_amd.config import ModelConfig
+from trace_amd.sampler import TraceSampler, C_PAD
+from trace_amd.weights import random_state_dict
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10240
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+bwd = (sys.argv[3] != "fwd") if len(sys.argv) > 3 else True
+cfg = ModelConfig(); s = TraceSampler(cfg, random_state_dict(cfg, 0), "cuda:0"); L = s.lib
+g = torch.Generator(device="cuda:0").manual_seed(0)
+x_in = torch.zeros(rows, C_PAD, 52, device="cuda:0"); x_in[:, :38] = torch.randn(rows, 38, 52, device="cuda:0", generator=g)
+cond = torch.randn(rows // 20, 256, device="cuda:0", generator=g)
+table = torch.empty(rows // 20, s.cond_width, device="cuda:0")
+_cabi.check(L.trace_unet_cond_table(s._unet, cond.data_ptr(), rows // 20, table.data_ptr(), None))
+wsb = L.trace_unet_workspace_bytes(s._unet, rows, 1); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda:0")
+pred = torch.empty(rows, 52, 2, device="cuda:0"); gp = torch.randn(rows, 52, 2, device="cuda:0", generator=g); gx = torch.empty(rows, 52, 2, device="cuda:0")
+for i in range(iters):
+    _cabi.check(L.trace_unet_forward(s._unet, x_in.data_ptr(), table.data_ptr(), 20, 50, rows, pred.data_ptr(), ws.data_ptr(), wsb, 1, None))
+    if bwd:
+        _cabi.check(L.trace_unet_backward_input(s._unet, gp.data_ptr(), rows, gx.data_ptr(), ws.data_ptr(), wsb, None))
+torch.cuda.synchronize()
+print("done", float(pred.abs().mean()), float(gx.abs().mean()) if bwd else 0)

@@ -58,6 +58,27 @@ __device__ __forceinline__ float mish_f(float x) {
   return x * (n / (n + 2.f));
 }
 
+// Same function on the hardware transcendental units (v_exp_f32 / v_rcp_f32, ~1 ulp each): used in
+// the conv epilogue, where the library expf + IEEE division cost more VALU cycles than the MFMAs of
+// the small-K layers they follow.  A bare v_exp_f32(x*log2e) loses |x|*6e-8 relative to the
+// rounding of the product (the noisy-guidance loop amplifies that beyond the parity bar), so the
+// product's rounding error and the low part of log2(e) are fed back through e^d ~ 1 + d.
+__device__ __forceinline__ float mish_fast_f(float x) {
+  const float L2E_HI = 1.44269502162933349609375f;   // float(log2 e)
+  const float L2E_LO = 1.92596299112661746e-8f;      // log2 e - L2E_HI
+  float xc = fminf(x, 20.f);
+  float p = xc * L2E_HI;
+  float d = __builtin_fmaf(xc, L2E_HI, -p) + xc * L2E_LO;      // exact remainder of the product
+  float e = __builtin_amdgcn_exp2f(p);
+  e = __builtin_fmaf(e, d * 0.693147182464599609375f, e);
+  float n = e * (e + 2.f);
+  float w = n + 2.f;
+  float r = __builtin_amdgcn_rcpf(w);
+  r = __builtin_fmaf(__builtin_fmaf(-w, r, 1.f), r, r);          // one Newton step: <= 0.5 ulp
+  float m = x * (n * r);
+  return x > 20.f ? x : m;
+}
+
 // d/dx mish(x) = tanh(sp) + x * sigmoid(x) * (1 - tanh(sp)^2),  1 - tanh^2 = 4(n+1)/(n+2)^2
 __device__ __forceinline__ float mish_grad_f(float x) {
   if (x > 20.f) return 1.f;

@@ -63,7 +63,8 @@ struct ConvGeom {
   static constexpr int R = TB * L_OUT;
   static constexpr int NRT = R / 16;
   static constexpr int LP = (L_OUT - 1) * IN_STRIDE + TAPS;
-  static constexpr int S = TB * LP;
+  static constexpr int S = TB * LP;                        // staged positions (with halo)
+  static constexpr int CHS = CH + 4;                       // LDS floats per position: CHS/4 odd
   static constexpr int L_IN = (L_OUT * IN_STRIDE) / UP;
   static constexpr int RS = R + 4;
   static constexpr int F4_PER_TRAJ = CH * L_IN / 4;        // float4 per trajectory per chunk
@@ -73,14 +74,16 @@ struct ConvGeom {
   static constexpr int NKK = TAPS * KBPC;
   static_assert(R % 16 == 0, "row block must be a whole number of MFMA tiles");
   static_assert((CH * L_IN) % 4 == 0 && CH % 16 == 0, "chunk must be float4 / k-block aligned");
+  static_assert((CHS / 4) % 2 == 1, "position stride must be an odd number of 16-byte slots");
   static constexpr size_t LDS_FLOATS =
-      ((size_t)CH * S > (size_t)64 * RS + 2 * TB * 8) ? (size_t)CH * S : (size_t)64 * RS + 2 * TB * 8;
+      ((size_t)CHS * S > (size_t)64 * RS + 2 * TB * 8 + 3 * TB * 64) ? (size_t)CHS * S
+                                                                      : (size_t)64 * RS + 2 * TB * 8 + 3 * TB * 64;
 };
 
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
-  constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, RS = G::RS;
+  constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, RS = G::RS, CHS = G::CHS;
   constexpr int NF4 = G::NF4, KBPC = G::KBPC, NKK = G::NKK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
           const int e = e0 + u;
           const int ci = e / L_IN;
           const int i = e - ci * L_IN;
-          lds[ci * S + tr * LP + i * UP + PADL] = stg[j][u];
+          lds[(tr * LP + i * UP + PADL) * CHS + ci] = stg[j][u];
         }
       }
     }
@@ -137,15 +140,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   stage_load(0);
   // halo / zero-stuffing positions are written once; data positions are the same for every chunk
 #pragma unroll 2
-  for (int i = tid; i < CH * S; i += 256) lds[i] = 0.f;
+  for (int i = tid; i < CHS * S / 4; i += 256)
+    reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // LDS image is [position][channel]; lane (row = lane&15, kq = lane>>4) reads the 4 channels
+  // 16m + 4kq .. +3 of its output row's input position with one ds_read_b128, and feeds element
+  // u to MFMA pass u (the host packs the weights in the matching k order)
   int rowoff[NRT];
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) {
     int r = rt * 16 + (lane & 15);
     int tr = r / L_OUT;
     int l = r - tr * L_OUT;
-    rowoff[rt] = tr * LP + l * IN_STRIDE + (lane >> 4) * S;
+    rowoff[rt] = (tr * LP + l * IN_STRIDE) * CHS + (lane >> 4) * 4;
   }
   f32x4 acc[NRT];
 #pragma unroll
@@ -161,10 +168,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     if (c0 + CH < a.cin) stage_load(c0 + CH);   // in flight during this chunk's K loop
     __syncthreads();
 
-    float a0[NRT], a1[NRT];
+    // K loop over the staged chunk.  One ds_read_b128 per (row tile, k-block) supplies the A
+    // values of 4 MFMA passes; the read for the NEXT k-block is issued right after the last pass
+    // that consumes the register, i.e. 13 MFMAs (>400 cycles) ahead of its first use.
+    f32x4 av[NRT];
     const float* lp = lds;
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) a0[rt] = lp[rowoff[rt]];
+    for (int rt = 0; rt < NRT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(lp + rowoff[rt]);
     int tap = 0, kb = 0;
     for (int kk = 0; kk < NKK; ++kk) {
       const f32x4 b = bnext;
@@ -173,31 +183,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
       if (kdone < a.nkb) bnext = *wp;
       int kb2 = kb + 1, tap2 = tap;
       if (kb2 == KBPC) { kb2 = 0; ++tap2; }
-      const float* lpn = lds + kb2 * 16 * S + tap2;
+      const float* lpn = lds + tap2 * CHS + kb2 * 16;
       const bool more = kk + 1 < NKK;
-      // 4 k-steps; A values for step s+1 are read while step s multiplies
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) a1[rt] = lp[rowoff[rt] + 4 * S];
+      for (int u = 0; u < 3; ++u) {
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], b[0], acc[rt], 0, 0, 0);
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) a0[rt] = lp[rowoff[rt] + 8 * S];
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], b[1], acc[rt], 0, 0, 0);
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) a1[rt] = lp[rowoff[rt] + 12 * S];
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[rt], b[2], acc[rt], 0, 0, 0);
-      if (more) {
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) a0[rt] = lpn[rowoff[rt]];
+        for (int rt = 0; rt < NRT; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][u], b[u], acc[rt], 0, 0, 0);
       }
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt)
-        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[rt], b[3], acc[rt], 0, 0, 0);
+      for (int rt = 0; rt < NRT; ++rt) {
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], b[3], acc[rt], 0, 0, 0);
+        if (more) av[rt] = *reinterpret_cast<const f32x4*>(lpn + rowoff[rt]);
+      }
       lp = lpn;
       kb = kb2;
       tap = tap2;
@@ -218,7 +216,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
-  float* stat = lds + 64 * RS;
+  float* stat = lds + 64 * RS;                 // [TB*8][2] group statistics
+  float* tab_scale = stat + 2 * TB * 8;        // [TB][64] rstd*gamma
+  float* tab_shift = tab_scale + TB * 64;      // [TB][64] beta - mean*rstd*gamma
+  float* tab_add = tab_shift + TB * 64;        // [TB][64] time/cond bias added after the Mish
   const int cg_shift = a.gn ? __builtin_ctz(a.cg) : 0;
   const int gps = a.gn ? (64 >> cg_shift) : 1;
   if (a.gn) {
@@ -258,33 +259,48 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     }
     __syncthreads();
   }
+  // per-(trajectory, channel) affine of the norm and the additive bias, built once
+  if (a.gn || a.pc) {
+    for (int idx = tid; idx < TB * 64; idx += 256) {
+      const int tr = idx >> 6, c = idx & 63, co = co0 + c;
+      const int tg = min(traj0 + tr, a.rows - 1);
+      if (a.gn) {
+        const int u = tr * gps + (c >> cg_shift);
+        const float sc = stat[2 * u + 1] * a.gamma[co];
+        tab_scale[idx] = sc;
+        tab_shift[idx] = a.beta[co] - stat[2 * u] * sc;
+      }
+      tab_add[idx] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + a.pt[co]
+                          : 0.f;
+    }
+    __syncthreads();
+  }
   // ---- normalise / activate / add / store (contiguous per trajectory) ---------------
+  constexpr int STEP_C = 256 / L_OUT, STEP_L = 256 % L_OUT;
   for (int tr = 0; tr < TB; ++tr) {
     const int tg = traj0 + tr;
     if (tg >= a.rows) break;
-    const float* pcrow =
-        a.pc ? a.pc + (size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co0 : nullptr;
     const float* resp =
         a.res ? a.res + (size_t)tg * a.res_tstride + (size_t)(a.res_coff + co0) * L_OUT : nullptr;
     const float* res2p =
         a.res2 ? a.res2 + (size_t)tg * a.res2_tstride + (size_t)(a.res2_coff + co0) * L_OUT : nullptr;
     float* outp = a.out + (size_t)tg * a.out_tstride + (size_t)(a.out_coff + co0) * L_OUT;
     float* ysp = a.ysave ? a.ysave + ((size_t)tg * a.cout + co0) * L_OUT : nullptr;
+    int c = tid / L_OUT;
+    int l = tid - c * L_OUT;
+    const float* ytile = lds + tr * L_OUT;
+    const int tb = tr * 64;
     for (int e = tid; e < 64 * L_OUT; e += 256) {
-      int c = e / L_OUT;
-      int l = e - c * L_OUT;
-      int co = co0 + c;
-      float y = lds[c * RS + tr * L_OUT + l];
+      float y = ytile[c * RS + l];
       if (ysp) ysp[e] = y;
-      if (a.gn) {
-        int u = tr * gps + (c >> cg_shift);
-        float z = (y - stat[2 * u]) * stat[2 * u + 1] * a.gamma[co] + a.beta[co];
-        y = mish_f(z);
-      }
-      if (pcrow) y += pcrow[c] + a.pt[co];
+      if (a.gn) y = mish_fast_f(fmaf(y, tab_scale[tb + c], tab_shift[tb + c]));
+      if (a.pc) y += tab_add[tb + c];
       if (resp) y += resp[e];
       if (res2p) y += res2p[e];
       outp[e] = y;
+      c += STEP_C;
+      l += STEP_L;
+      if (l >= L_OUT) { l -= L_OUT; ++c; }
     }
   }
 }

@@ -268,7 +268,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
         for (int kb = 0; kb < kbpc; ++kb, ++kblk)
           for (int lane = 0; lane < 64; ++lane)
             for (int s = 0; s < 4; ++s) {
-              int ci = c0 + kb * 16 + s * 4 + (lane >> 4);
+              int ci = c0 + kb * 16 + (lane >> 4) * 4 + s;   // pass s of lane group kq = lane>>4
               int co = ct * 16 + (lane & 15);
               float v = ci < cin_real ? get(tap, ci, co) : 0.f;
               h[(((size_t)ct * nkb + kblk) * 64 + lane) * 4 + s] = v;
