@@ -166,9 +166,17 @@ def main():
         _cabi.check(L.trace_profile_end(C.byref(ms), C.byref(nl), C.byref(fl)), "trace_profile_end")
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
         peak = 157.3
+        # HBM bytes per launch cannot be counted from inside this process: the value comes from the
+        # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, corrected as
+        # MI355X_MICROARCH.md prescribes), null when that summary is absent.
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = float(json.load(f)["hbm_bytes_per_launch"])
         roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)",
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "traffic": None, "launches": int(nl.value),
+                    "traffic": traffic, "launches": int(nl.value),
                     "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
                     "conv_ms_per_ddpm_step": ms.value / n_prof_steps}
     if world > 1:
