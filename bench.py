@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--scenes", type=int, default=None, help="override scenes per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="keep the observation batch in host memory (PCIe-inclusive rate; not the headline)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +114,7 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.scenes is not None:
         wl["scenes"] = args.scenes
-    aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, device)
+    aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, None if args.host_inputs else device)
     N = wl["samples"]
     B = sum(aps)
     M = B * N
@@ -189,7 +191,8 @@ def main():
             "value": total / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic (seeded ORCA-style scenes, random-init orca_mixed weights)",
+            "data": "synthetic (seeded ORCA-style scenes, random-init orca_mixed weights)"
+                    + ("; inputs in HOST memory, PCIe copy inside the timed region" if args.host_inputs else ""),
             "config": {"workload": args.workload, "agents_per_gpu": B, "samples_per_agent": N,
                        "trajectories_per_gpu": M, "ddpm_steps": cfg.n_diffusion_steps,
                        "horizon": cfg.horizon, "class_free_guide_w": wl["w"],

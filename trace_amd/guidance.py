@@ -197,7 +197,14 @@ class GuidancePlan:
         cover = torch.zeros(B, dtype=torch.long)
         for inst in self.instances:
             cover += inst.mask.long()
-        self.sel_valid = ((cover == n_guides[sid]) & (n_guides[sid] > 0)).to(device)
+        valid = (cover == n_guides[sid]) & (n_guides[sid] > 0)
+        # Reference behaviour kept on purpose: for a scene with an EMPTY guide list the slice of
+        # losses is zero-width, so its NaN test passes for every agent of the batch and
+        # act_idx[all] = 0 (guidance_loss.py:26-39) -- the choices of all earlier scenes are reset.
+        empty = torch.nonzero(n_guides == 0, as_tuple=True)[0]
+        if empty.numel() > 0:
+            valid &= sid > int(empty.max())
+        self.sel_valid = valid.to(device)
         scene_level = torch.tensor([any(c.name in SCENE_LEVEL for c in g) for g in guidance.guide_configs])
         self.sel_scene_level = scene_level[sid].to(device)
         self.sel_scene_id = sid.to(device)

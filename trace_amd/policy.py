@@ -7,9 +7,10 @@ Mirrors (same names, argument meaning and return structure):
                                           -- /root/reference/tbsim/algos/algos.py:261-326
   * ``Diffuser`` composer               -- /root/reference/tbsim/evaluation/policy_composers.py:27-57
 
-The ``tbsim/`` package at the repo root re-exports these under the reference's import paths
-(``tbsim.evaluation.policy_composers.Diffuser`` ...), which is how
-``scripts/scene_editor.py --eval_class Diffuser`` resolves them (scene_editor.py:48-51).
+``trace_amd/compat/tbsim/`` re-exports these under the reference's import paths
+(``tbsim.evaluation.policy_composers.Diffuser`` ...) when ``trace_amd/compat`` is put on
+PYTHONPATH, which is how a driver written like ``scripts/scene_editor.py --eval_class Diffuser``
+resolves them (scene_editor.py:48-51).
 """
 import json
 import os
