@@ -7,15 +7,19 @@
 //   cols   = 64 output channels per workgroup (4 waves x one 16-wide MFMA column tile)
 //   K      = taps x input channels, streamed in chunks of CH (<=64) channels through LDS
 //
-// A operand: activations staged once per chunk into LDS, channel-major with zeroed halo /
-//            zero-stuffing, read with ds_read_b32 (lanes = consecutive positions: conflict-free),
-//            software-pipelined one k-step (13 reads) ahead of the MFMAs that consume them
+// A operand: activations staged once per chunk into LDS as [position][channel] (zeroed halo /
+//            zero-stuffing, position stride CH+4 floats), read with one conflict-free ds_read_b128
+//            per (row tile, k-block) that feeds 4 MFMA passes; the reads of the next k-block are
+//            issued during the last pass of the current one
 // B operand: weights pre-packed on the host in MFMA fragment order, streamed L2 -> VGPR with one
-//            coalesced dwordx4 per 16 k (no LDS, no barrier in the K loop), prefetched one
-//            k-block ahead
-// staging  : the next chunk's activations are fetched global -> VGPR (dwordx4) before the K loop
-//            of the current chunk and written to LDS after it (issue early / write late), so HBM
-//            / L2 latency hides under the MFMAs
+//            coalesced dwordx4 per 16 k (no LDS, no barrier in the K loop), prefetched two
+//            k-blocks ahead so that its wait never covers the (older) staging loads
+// staging  : the next chunk's activations are fetched global -> VGPR (buffer_load b128) before
+//            the K loop of the current chunk and written to LDS after it (issue early / write
+//            late), so HBM / L2 latency hides under the MFMAs
+// epilogue : accumulators -> LDS tile laid out like the global tensor; GroupNorm statistics from
+//            registers (one (trajectory, channel) row per thread, butterfly over the group);
+//            normalise + Mish + cond/time bias + residual(s) and 128-bit stores in one flat pass
 #pragma once
 #include "common.h"
 
@@ -75,15 +79,16 @@ struct ConvGeom {
   static_assert(R % 16 == 0, "row block must be a whole number of MFMA tiles");
   static_assert((CH * L_IN) % 4 == 0 && CH % 16 == 0, "chunk must be float4 / k-block aligned");
   static_assert((CHS / 4) % 2 == 1, "position stride must be an odd number of 16-byte slots");
-  static constexpr size_t LDS_FLOATS =
-      ((size_t)CHS * S > (size_t)64 * RS + 2 * TB * 8 + 3 * TB * 64) ? (size_t)CHS * S
-                                                                      : (size_t)64 * RS + 2 * TB * 8 + 3 * TB * 64;
+  static constexpr int NQ = R * 64 / 4 / 256;              // output float4 per thread
+  static_assert(R * 64 % 1024 == 0 && TB % 4 == 0, "output tile must split evenly over 256 threads");
+  static constexpr size_t EPI_FLOATS = (size_t)R * 64 + (size_t)TB * 64 * 4;   // tile + tables
+  static constexpr size_t LDS_FLOATS = ((size_t)CHS * S > EPI_FLOATS) ? (size_t)CHS * S : EPI_FLOATS;
 };
 
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
-  constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, RS = G::RS, CHS = G::CHS;
+  constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, R = G::R, CHS = G::CHS;
   constexpr int NF4 = G::NF4, KBPC = G::KBPC, NKK = G::NKK;
   extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
 
   const f32x4* wp = a.wp + ((size_t)(blockIdx.y * 4 + wave) * a.nkb) * 64 + lane;
   f32x4 bnext = *wp;
+  f32x4 bnext2 = a.nkb > 1 ? wp[64] : bnext;
   int kdone = 0;
 
   for (int c0 = 0; c0 < a.cin; c0 += CH) {
@@ -178,9 +184,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     int tap = 0, kb = 0;
     for (int kk = 0; kk < NKK; ++kk) {
       const f32x4 b = bnext;
+      bnext = bnext2;
       ++kdone;
       wp += 64;
-      if (kdone < a.nkb) bnext = *wp;
+      if (kdone + 1 < a.nkb) bnext2 = wp[64];
       int kb2 = kb + 1, tap2 = tap;
       if (kb2 == KBPC) { kb2 = 0; ++tap2; }
       const float* lpn = lds + tap2 * CHS + kb2 * 16;
@@ -202,106 +209,183 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     }
   }
 
-  // ---- epilogue: accumulators -> LDS [co][row] -------------------------------------
+  // ---- epilogue --------------------------------------------------------------------------
+  // The 208 x 64 accumulator tile goes through LDS once, laid out exactly like the global
+  // tensors ([trajectory][channel][position], TILE floats per trajectory), so that
+  //   E1  per-(trajectory, channel) rows are contiguous  -> GroupNorm statistics in registers
+  //   E2  the whole tile is one flat stream              -> 128-bit LDS reads and global accesses
+  // Residual operands are fetched into registers before anything else: their latency hides
+  // under E0/E1 instead of serialising the store loop.
+  constexpr int TILE = 64 * L_OUT;
+  constexpr int NQ = G::NQ;
+  const bool has_tab = a.gn || a.pc;
+  auto flat_off = [&](int k, int tstride, int coff, int& rem_out) -> unsigned {
+    const int f = (tid + 256 * k) * 4;
+    const int tr = f / TILE;
+    const int rem = f - tr * TILE;
+    rem_out = rem;
+    const int tg = traj0 + tr;
+    return tg < a.rows ? (unsigned)((tg * tstride + (coff + co0) * L_OUT + rem) * 4) : 0xffffffffu;
+  };
+  f32x4 rv[NQ];
+  if (a.res) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res), 0, (unsigned)((size_t)a.rows * a.res_tstride * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      int rem;
+      rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rr, flat_off(k, a.res_tstride, a.res_coff, rem), 0, 0));
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (a.res2) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res2), 0, (unsigned)((size_t)a.rows * a.res2_tstride * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      int rem;
+      f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              rr, flat_off(k, a.res2_tstride, a.res2_coff, rem), 0, 0));
+      rv[k] += t;
+    }
+  }
+
+  // E0: accumulators (+ conv bias) -> LDS tile
   __syncthreads();
   {
     const int col = lane & 15, q = lane >> 4;
     const int co_l = wave * 16 + col;
     const float bv = a.bias ? a.bias[co0 + co_l] : 0.f;
+    float* tcol = lds + co_l * L_OUT;
+    int tr = 0, l = q * 4;                      // row r = rt*16 + q*4 + reg = tr*L_OUT + l
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
-      f32x4 v = acc[rt];
-      v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv;
-      *reinterpret_cast<f32x4*>(&lds[co_l * RS + rt * 16 + q * 4]) = v;
+      if constexpr (L_OUT % 4 == 0) {           // a quad of rows never straddles two trajectories
+        f32x4 v = acc[rt];
+        v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv;
+        *reinterpret_cast<f32x4*>(tcol + tr * TILE + l) = v;
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          int ll = l + reg, t2 = tr;
+          if (ll >= L_OUT) { ll -= L_OUT; ++t2; }
+          tcol[t2 * TILE + ll] = acc[rt][reg] + bv;
+        }
+      }
+      l += 16;
+      tr += l / L_OUT;
+      l %= L_OUT;
     }
   }
   __syncthreads();
-  float* stat = lds + 64 * RS;                 // [TB*8][2] group statistics
-  float* tab_scale = stat + 2 * TB * 8;        // [TB][64] rstd*gamma
-  float* tab_shift = tab_scale + TB * 64;      // [TB][64] beta - mean*rstd*gamma
-  float* tab_add = tab_shift + TB * 64;        // [TB][64] time/cond bias added after the Mish
-  const int cg_shift = a.gn ? __builtin_ctz(a.cg) : 0;
-  const int gps = a.gn ? (64 >> cg_shift) : 1;
-  if (a.gn) {
-    const int nunits = TB * gps;
-    const int n = a.cg * L_OUT;
-    const float inv_n = 1.f / (float)n;
-    for (int u = wave; u < nunits; u += 4) {
-      int tr = u / gps;
-      int g = u - tr * gps;
-      const float* base = lds + (g * a.cg) * RS + tr * L_OUT;
-      float s = 0.f;
-      for (int e = lane; e < n; e += 64) {
-        int c = e / L_OUT;
-        int l = e - c * L_OUT;
-        s += base[c * RS + l];
-      }
-      float mean = wave_sum(s) * inv_n;
-      float v = 0.f;
-      for (int e = lane; e < n; e += 64) {
-        int c = e / L_OUT;
-        int l = e - c * L_OUT;
-        float d = base[c * RS + l] - mean;
-        v += d * d;
-      }
-      float var = wave_sum(v) * inv_n;
-      float rstd = 1.f / sqrtf(var + 1e-5f);
-      if (lane == 0) {
-        stat[2 * u] = mean;
-        stat[2 * u + 1] = rstd;
-        int tg = traj0 + tr;
-        if (a.stats && tg < a.rows) {
-          size_t si = ((size_t)tg * (a.cout >> cg_shift) + ((co0 >> cg_shift) + g)) * 2;
+
+  // E1: one (trajectory, channel) row per thread and pass; lanes = the 64 channels, so the
+  // channels of a group are neighbouring lanes and the group reduction is a butterfly.
+  f32x4* tab = reinterpret_cast<f32x4*>(lds + R * 64);      // [TB][64] {scale, shift, add, -}
+  if (has_tab) {
+    constexpr int NP = TB / 4;
+    const int c = lane, co = co0 + c;
+    const float gam = a.gn ? a.gamma[co] : 1.f;
+    const float bet = a.gn ? a.beta[co] : 0.f;
+    const float ptv = a.pc ? a.pt[co] : 0.f;
+    const int cg = a.gn ? a.cg : 1;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int tr = wave + 4 * j;
+      const int tg = min(traj0 + tr, a.rows - 1);
+      float scale = 1.f, shift = 0.f;
+      if (a.gn) {
+        const float* row = lds + (tr * 64 + c) * L_OUT;
+        float v[L_OUT];
+        if constexpr (L_OUT % 4 == 0) {
+#pragma unroll
+          for (int i = 0; i < L_OUT / 4; ++i) {
+            f32x4 t = reinterpret_cast<const f32x4*>(row)[i];
+            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
+          }
+        } else if constexpr (L_OUT % 2 == 0) {
+#pragma unroll
+          for (int i = 0; i < L_OUT / 2; ++i) {
+            float2 t = reinterpret_cast<const float2*>(row)[i];
+            v[2 * i] = t.x; v[2 * i + 1] = t.y;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < L_OUT; ++i) v[i] = row[i];
+        }
+        // exact two-level moments: row mean / centred sum of squares, then Chan's combination
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) s += v[i];
+        const float rmean = s * (1.f / (float)L_OUT);
+        float m2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) {
+          const float d = v[i] - rmean;
+          m2 = fmaf(d, d, m2);
+        }
+        float gs = rmean;
+        for (int m = 1; m < cg; m <<= 1) gs += __shfl_xor(gs, m);
+        const float mean = gs / (float)cg;
+        const float dm = rmean - mean;
+        float gv = fmaf(dm * dm, (float)L_OUT, m2);
+        for (int m = 1; m < cg; m <<= 1) gv += __shfl_xor(gv, m);
+        const float var = gv / (float)(cg * L_OUT);
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        scale = rstd * gam;
+        shift = bet - mean * scale;
+        if (a.stats && (c & (cg - 1)) == 0 && traj0 + tr < a.rows) {
+          const int cgs = __builtin_ctz(cg);
+          const size_t si = ((size_t)(traj0 + tr) * (a.cout >> cgs) + (co >> cgs)) * 2;
           a.stats[si] = mean;
           a.stats[si + 1] = rstd;
         }
       }
+      const float add =
+          a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
+      tab[tr * 64 + c] = f32x4{scale, shift, add, 0.f};
     }
     __syncthreads();
   }
-  // per-(trajectory, channel) affine of the norm and the additive bias, built once
-  if (a.gn || a.pc) {
-    for (int idx = tid; idx < TB * 64; idx += 256) {
-      const int tr = idx >> 6, c = idx & 63, co = co0 + c;
-      const int tg = min(traj0 + tr, a.rows - 1);
-      if (a.gn) {
-        const int u = tr * gps + (c >> cg_shift);
-        const float sc = stat[2 * u + 1] * a.gamma[co];
-        tab_scale[idx] = sc;
-        tab_shift[idx] = a.beta[co] - stat[2 * u] * sc;
+
+  // E2: flat pass -- normalise / activate / add / store, 4 consecutive outputs per access
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+      a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      a.ysave ? a.ysave : a.out, 0,
+      a.ysave ? (unsigned)((size_t)a.rows * a.cout * L_OUT * sizeof(float)) : 0u, 0x00020000);
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    const int f = (tid + 256 * k) * 4;
+    f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+    int rem;
+    const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
+    if (a.ysave) {
+      int rem2;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y),
+                                             ry, flat_off(k, a.cout * L_OUT, 0, rem2), 0, 0);
+    }
+    if (has_tab) {
+      const int tr = f / TILE;
+      const int c0 = rem / L_OUT;
+      const int l0 = rem - c0 * L_OUT;
+      const f32x4 t0 = tab[tr * 64 + c0];
+      f32x4 t1 = t0;
+      if constexpr (L_OUT % 4 != 0) t1 = tab[tr * 64 + min(c0 + 1, 63)];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool hi = (L_OUT % 4 != 0) && (l0 + i >= L_OUT);
+        const float sc = hi ? t1[0] : t0[0], sh = hi ? t1[1] : t0[1], ad = hi ? t1[2] : t0[2];
+        float z = fmaf(y[i], sc, sh);
+        if (a.gn) z = mish_fast_f(z);
+        y[i] = z + ad;
       }
-      tab_add[idx] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + a.pt[co]
-                          : 0.f;
     }
-    __syncthreads();
-  }
-  // ---- normalise / activate / add / store (contiguous per trajectory) ---------------
-  constexpr int STEP_C = 256 / L_OUT, STEP_L = 256 % L_OUT;
-  for (int tr = 0; tr < TB; ++tr) {
-    const int tg = traj0 + tr;
-    if (tg >= a.rows) break;
-    const float* resp =
-        a.res ? a.res + (size_t)tg * a.res_tstride + (size_t)(a.res_coff + co0) * L_OUT : nullptr;
-    const float* res2p =
-        a.res2 ? a.res2 + (size_t)tg * a.res2_tstride + (size_t)(a.res2_coff + co0) * L_OUT : nullptr;
-    float* outp = a.out + (size_t)tg * a.out_tstride + (size_t)(a.out_coff + co0) * L_OUT;
-    float* ysp = a.ysave ? a.ysave + ((size_t)tg * a.cout + co0) * L_OUT : nullptr;
-    int c = tid / L_OUT;
-    int l = tid - c * L_OUT;
-    const float* ytile = lds + tr * L_OUT;
-    const int tb = tr * 64;
-    for (int e = tid; e < 64 * L_OUT; e += 256) {
-      float y = ytile[c * RS + l];
-      if (ysp) ysp[e] = y;
-      if (a.gn) y = mish_fast_f(fmaf(y, tab_scale[tb + c], tab_shift[tb + c]));
-      if (a.pc) y += tab_add[tb + c];
-      if (resp) y += resp[e];
-      if (res2p) y += res2p[e];
-      outp[e] = y;
-      c += STEP_C;
-      l += STEP_L;
-      if (l >= L_OUT) { l -= L_OUT; ++c; }
-    }
+    y += rv[k];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y), ro, oo, 0, 0);
   }
 }
 
@@ -320,6 +404,17 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
   TRACE_REQUIRE((size_t)a.rows * a.in_tstride * sizeof(float) < 0xffffffffull,
                 "conv: input of %d rows exceeds the 4 GiB buffer-descriptor range; split the rows",
                 a.rows);
+  // the epilogue moves 4 consecutive outputs per access through buffer descriptors
+  auto ok128 = [&](const float* p, int tstride, int coff) {
+    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 &&
+                            (coff * L_OUT) % 4 == 0 &&
+                            (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
+  };
+  TRACE_REQUIRE(ok128(a.out, a.out_tstride, a.out_coff) && ok128(a.res, a.res_tstride, a.res_coff) &&
+                    ok128(a.res2, a.res2_tstride, a.res2_coff) && ok128(a.ysave, a.cout * L_OUT, 0),
+                "conv: output / residual tensors must be 16-byte aligned per trajectory tile and "
+                "below 4 GiB (%d rows)", a.rows);
+  TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
   constexpr size_t lds_bytes = G::LDS_FLOATS * sizeof(float);
   // two workgroups per CU must fit in the 160 KiB LDS
   static_assert(lds_bytes <= 80 * 1024, "conv: LDS per workgroup too large");
