@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 #include "trace_hip.h"
 
@@ -88,6 +89,29 @@ __device__ __forceinline__ float mish_grad_f(float x) {
   float tsp = n / w;
   float sig = e / (1.f + e);
   return tsp + x * sig * (4.f * (n + 1.f) / (w * w));
+}
+
+// mish'(x) on the hardware transcendental units, same compensated exponent and Newton-refined
+// reciprocals as mish_fast_f (fused GroupNorm/Mish backward epilogue of the dgrad convs).
+__device__ __forceinline__ float mish_grad_fast_f(float x) {
+  const float L2E_HI = 1.44269502162933349609375f;
+  const float L2E_LO = 1.92596299112661746e-8f;
+  float xc = fminf(x, 20.f);
+  float p = xc * L2E_HI;
+  float d = __builtin_fmaf(xc, L2E_HI, -p) + xc * L2E_LO;
+  float e = __builtin_amdgcn_exp2f(p);
+  e = __builtin_fmaf(e, d * 0.693147182464599609375f, e);
+  float n = e * (e + 2.f);
+  float w = n + 2.f;
+  float r = __builtin_amdgcn_rcpf(w);
+  r = __builtin_fmaf(__builtin_fmaf(-w, r, 1.f), r, r);
+  float e1 = 1.f + e;
+  float q = __builtin_amdgcn_rcpf(e1);
+  q = __builtin_fmaf(__builtin_fmaf(-e1, q, 1.f), q, q);
+  float tsp = n * r;
+  float sig = e * q;
+  float g = tsp + x * sig * (4.f * (n + 1.f) * (r * r));
+  return x > 20.f ? 1.f : g;
 }
 
 }  // namespace trace

@@ -60,6 +60,26 @@ struct ConvArgs {
   int res2_tstride;
   int res2_coff;
   double alg_macs_per_pos;   // algorithmic MACs per (row, output position): cout * cin_real * taps_alg
+  // second K source: cin2 more input channels taken from in2 at the centre tap only (the 1x1
+  // residual conv of a block folded into the k5 dgrad of the same block); weights appended
+  const float* in2;
+  int in2_tstride;
+  int in2_coff;
+  int cin2;            // multiple of chunk, 0 = none
+  // GroupNorm + Mish BACKWARD epilogue: v = acc + res + res2 is the gradient w.r.t. the Mish output
+  // of the layer that produced this conv's (forward) input; out <- d/dy of that layer's
+  // pre-norm output y, out_raw <- v (needed again by the residual / skip paths)
+  int gnb;
+  int gb_cmax;         // only output channels < gb_cmax go through the norm (rest: out_raw only)
+  const float* gb_y;   // saved pre-norm output [rows][gb_c][L_OUT]
+  const float* gb_stats;
+  const float* gb_gamma;
+  const float* gb_beta;
+  int gb_cg;
+  int gb_c;
+  float* out_raw;      // or null
+  int raw_tstride;
+  int raw_coff;
 };
 
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
@@ -104,23 +124,32 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
       0x00020000);
-  unsigned soff[NF4];
+  const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in2 ? a.in2 : a.in), 0,
+      a.in2 ? (unsigned)((size_t)a.rows * a.in2_tstride * sizeof(float)) : 0u, 0x00020000);
+  const int nch1 = a.cin / CH;
+  const int nch = nch1 + a.cin2 / CH;
+  unsigned spk[NF4];            // (trajectory in tile) << 20 | float offset inside the chunk
 #pragma unroll
   for (int j = 0; j < NF4; ++j) {
     const int q = tid + 256 * j;
     const int tr = q / G::F4_PER_TRAJ;
     const int rem = q - tr * G::F4_PER_TRAJ;
-    soff[j] = q < G::F4_TOTAL
-                  ? (unsigned)(((traj0 + tr) * a.in_tstride + a.in_coff * L_IN + rem * 4) * 4)
-                  : 0xffffffffu;     // out of range -> zeros
+    spk[j] = q < G::F4_TOTAL ? ((unsigned)tr << 20) | (unsigned)(rem * 4) : 0xffffffffu;
   }
   f32x4 stg[NF4];
-  auto stage_load = [&](int c0) {
-    const unsigned cb = (unsigned)(c0 * L_IN * 4);
+  auto stage_load = [&](int ch) {
+    const bool second = ch >= nch1;
+    const int tstride = second ? a.in2_tstride : a.in_tstride;
+    const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
+                      traj0 * tstride;
 #pragma unroll
     for (int j = 0; j < NF4; ++j) {
-      auto v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, soff[j] == 0xffffffffu ? soff[j] : soff[j] + cb,
-                                                     0, 0);
+      const unsigned off = spk[j] == 0xffffffffu
+                               ? 0xffffffffu     // out of range -> zeros
+                               : (unsigned)(((int)(spk[j] >> 20) * tstride + (int)(spk[j] & 0xfffffu) + cbase) * 4);
+      auto v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
       stg[j] = __builtin_bit_cast(f32x4, v);
     }
   };
@@ -168,21 +197,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   f32x4 bnext2 = a.nkb > 1 ? wp[64] : bnext;
   int kdone = 0;
 
-  for (int c0 = 0; c0 < a.cin; c0 += CH) {
+  for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();            // previous chunk fully consumed (and zero fill done)
     stage_write();
-    if (c0 + CH < a.cin) stage_load(c0 + CH);   // in flight during this chunk's K loop
+    if (ch + 1 < nch) stage_load(ch + 1);       // in flight during this chunk's K loop
     __syncthreads();
 
     // K loop over the staged chunk.  One ds_read_b128 per (row tile, k-block) supplies the A
     // values of 4 MFMA passes; the read for the NEXT k-block is issued right after the last pass
     // that consumes the register, i.e. 13 MFMAs (>400 cycles) ahead of its first use.
+    // Chunks of the second source contribute at the centre tap only.
+    const bool second = ch >= nch1;
+    int kk = second ? PADL * KBPC : 0;
+    const int kk_end = second ? (PADL + 1) * KBPC : NKK;
+    int tap = second ? PADL : 0, kb = 0;
     f32x4 av[NRT];
-    const float* lp = lds;
+    const float* lp = lds + tap * CHS;
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(lp + rowoff[rt]);
-    int tap = 0, kb = 0;
-    for (int kk = 0; kk < NKK; ++kk) {
+    for (; kk < kk_end; ++kk) {
       const f32x4 b = bnext;
       bnext = bnext2;
       ++kdone;
@@ -191,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
       int kb2 = kb + 1, tap2 = tap;
       if (kb2 == KBPC) { kb2 = 0; ++tap2; }
       const float* lpn = lds + tap2 * CHS + kb2 * 16;
-      const bool more = kk + 1 < NKK;
+      const bool more = kk + 1 < kk_end;
 #pragma unroll
       for (int u = 0; u < 3; ++u) {
 #pragma unroll
@@ -281,6 +314,111 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
+
+  typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+  if (a.gnb) {
+    // ---- GroupNorm + Mish backward epilogue (input-VJP) ---------------------------------
+    // G1 (flat): v = tile + residuals; raw copy out; v back into the tile
+    const bool normed = co0 < a.gb_cmax;
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        a.out_raw ? a.out_raw : a.out, 0,
+        a.out_raw ? (unsigned)((size_t)a.rows * a.raw_tstride * sizeof(float)) : 0u, 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int f = (tid + 256 * k) * 4;
+      f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+      y += rv[k];
+      if (a.out_raw) {
+        int rem;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rw,
+                                               flat_off(k, a.raw_tstride, a.raw_coff, rem), 0, 0);
+      }
+      *reinterpret_cast<f32x4*>(lds + f) = y;
+    }
+    if (!normed) return;                       // uniform per workgroup
+    __syncthreads();
+    // G2 (rows): thread = one (trajectory, channel) row, lanes = channels
+    {
+      constexpr int NP = TB / 4;
+      const int c = lane, co = co0 + c;
+      const int cg = a.gb_cg, cgs = __builtin_ctz(cg);
+      const float gam = a.gb_gamma[co], bet = a.gb_beta[co];
+      const float inv_n = 1.f / (float)(cg * L_OUT);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int tr = wave + 4 * j;
+        const int tg = min(traj0 + tr, a.rows - 1);
+        float* row = lds + (tr * 64 + c) * L_OUT;
+        const float* yrow = a.gb_y + ((size_t)tg * a.gb_c + co) * L_OUT;
+        const float* stp = a.gb_stats + ((size_t)tg * (a.gb_c >> cgs) + (co >> cgs)) * 2;
+        const float mean = stp[0], rstd = stp[1];
+        float gz[L_OUT], xh[L_OUT];
+        if constexpr (L_OUT % 4 == 0) {
+#pragma unroll
+          for (int i = 0; i < L_OUT / 4; ++i) {
+            const f32x4 t = reinterpret_cast<const f32x4*>(row)[i];
+            const f32x4 w = reinterpret_cast<const f32x4*>(yrow)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gz[4 * i + e] = t[e]; xh[4 * i + e] = w[e]; }
+          }
+        } else if constexpr (L_OUT % 2 == 0) {
+#pragma unroll
+          for (int i = 0; i < L_OUT / 2; ++i) {
+            const float2 t = reinterpret_cast<const float2*>(row)[i];
+            const float2 w = reinterpret_cast<const float2*>(yrow)[i];
+            gz[2 * i] = t.x; gz[2 * i + 1] = t.y; xh[2 * i] = w.x; xh[2 * i + 1] = w.y;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < L_OUT; ++i) { gz[i] = row[i]; xh[i] = yrow[i]; }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) {
+          const float x = (xh[i] - mean) * rstd;
+          const float z = fmaf(x, gam, bet);
+          const float d = gz[i] * mish_grad_fast_f(z) * gam;
+          gz[i] = d;
+          xh[i] = x;
+          s1 += d;
+          s2 = fmaf(d, x, s2);
+        }
+        for (int m = 1; m < cg; m <<= 1) {
+          s1 += __shfl_xor(s1, m);
+          s2 += __shfl_xor(s2, m);
+        }
+        s1 *= inv_n;
+        s2 *= inv_n;
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) gz[i] = rstd * (gz[i] - s1 - xh[i] * s2);
+        if constexpr (L_OUT % 4 == 0) {
+#pragma unroll
+          for (int i = 0; i < L_OUT / 4; ++i)
+            reinterpret_cast<f32x4*>(row)[i] = f32x4{gz[4 * i], gz[4 * i + 1], gz[4 * i + 2], gz[4 * i + 3]};
+        } else if constexpr (L_OUT % 2 == 0) {
+#pragma unroll
+          for (int i = 0; i < L_OUT / 2; ++i)
+            reinterpret_cast<float2*>(row)[i] = float2{gz[2 * i], gz[2 * i + 1]};
+        } else {
+#pragma unroll
+          for (int i = 0; i < L_OUT; ++i) row[i] = gz[i];
+        }
+      }
+    }
+    __syncthreads();
+    // G3 (flat): d/dy out
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+        a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int f = (tid + 256 * k) * 4;
+      const f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+      int rem;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro,
+                                             flat_off(k, a.out_tstride, a.out_coff, rem), 0, 0);
+    }
+    return;
+  }
 
   // E1: one (trajectory, channel) row per thread and pass; lanes = the 64 channels, so the
   // channels of a group are neighbouring lanes and the group reduction is a butterfly.
@@ -390,18 +528,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
 }
 
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
-int launch_conv(const ConvArgs& a, hipStream_t st) {
+int launch_conv(const ConvArgs& a_in, hipStream_t st) {
   using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
+  ConvArgs a = a_in;
   if (a.rows <= 0) return TRACE_OK;
-  TRACE_REQUIRE(a.cout % 64 == 0 && a.chunk == CH && a.cin % CH == 0 && a.nkb == TAPS * a.cin / 16,
-                "conv: bad channel geometry cin=%d chunk=%d cout=%d nkb=%d", a.cin, a.chunk, a.cout,
-                a.nkb);
+  TRACE_REQUIRE(a.cout % 64 == 0 && a.chunk == CH && a.cin % CH == 0 && a.cin2 % CH == 0 &&
+                    a.nkb == TAPS * a.cin / 16 + a.cin2 / 16,
+                "conv: bad channel geometry cin=%d cin2=%d chunk=%d cout=%d nkb=%d", a.cin, a.cin2,
+                a.chunk, a.cout, a.nkb);
+  TRACE_REQUIRE(a.cin2 == 0 || (a.in2 && IN_STRIDE == 1 && UP == 1 && a.in2_tstride % 4 == 0 &&
+                                a.in2_coff % 16 == 0 && (reinterpret_cast<uintptr_t>(a.in2) & 15) == 0 &&
+                                (size_t)(a.rows + TB) * a.in2_tstride * sizeof(float) < 0xffffffffull),
+                "conv: second K source needs a stride-1 conv and an aligned tensor below 4 GiB");
+  TRACE_REQUIRE(!a.gnb || (!a.gn && !a.pc && !a.ysave && a.gb_y && a.gb_stats && a.gb_gamma && a.gb_beta &&
+                           a.gb_cg > 0 && (a.gb_cg & (a.gb_cg - 1)) == 0 && a.gb_cg <= 64 &&
+                           a.gb_cmax % 64 == 0 && a.gb_cmax <= a.gb_c &&
+                           (reinterpret_cast<uintptr_t>(a.gb_y) & 15) == 0),
+                "conv: bad GroupNorm-backward epilogue arguments");
   TRACE_REQUIRE(!a.gn || (a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64), "conv: group size %d",
                 a.cg);
   TRACE_REQUIRE(a.in_tstride % 4 == 0 && a.in_coff % 16 == 0 &&
                     (reinterpret_cast<uintptr_t>(a.in) & 15) == 0,
                 "conv: input must be 16-byte aligned per trajectory chunk");
-  TRACE_REQUIRE((size_t)a.rows * a.in_tstride * sizeof(float) < 0xffffffffull,
+  TRACE_REQUIRE((size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull,
                 "conv: input of %d rows exceeds the 4 GiB buffer-descriptor range; split the rows",
                 a.rows);
   // the epilogue moves 4 consecutive outputs per access through buffer descriptors
@@ -411,7 +560,8 @@ int launch_conv(const ConvArgs& a, hipStream_t st) {
                             (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
   };
   TRACE_REQUIRE(ok128(a.out, a.out_tstride, a.out_coff) && ok128(a.res, a.res_tstride, a.res_coff) &&
-                    ok128(a.res2, a.res2_tstride, a.res2_coff) && ok128(a.ysave, a.cout * L_OUT, 0),
+                    ok128(a.res2, a.res2_tstride, a.res2_coff) && ok128(a.ysave, a.cout * L_OUT, 0) &&
+                    ok128(a.out_raw, a.raw_tstride, a.raw_coff),
                 "conv: output / residual tensors must be 16-byte aligned per trajectory tile and "
                 "below 4 GiB (%d rows)", a.rows);
   TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");

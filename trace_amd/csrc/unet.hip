@@ -188,12 +188,14 @@ struct PackedConv {
   int taps = 0;
   int chunk = 0;
   int nkb = 0;
+  int cin2 = 0;        // channels of the appended centre-tap source
 };
 
 struct Block {
   int cin, cout, L, level;
   PackedConv c1f, c2f, rf;   // forward
-  PackedConv c1b, c2b, rb;   // input-VJP (dgrad); c1b unused for the first block
+  PackedConv c1b, c2b;       // input-VJP (dgrad); c1b unused for the first block, and carries the
+                             // residual 1x1 conv's dgrad as a second K source when has_res
   bool has_res;
   float *b1, *g1, *be1, *b2, *g2, *be2, *br;
   int emb_off;  // offset into the cond table / step table
@@ -251,28 +253,37 @@ int upload(trace_unet* u, const std::vector<T>& h, T** out) {
 }
 
 // get(tap, ci, co) -> weight of the GEMM B matrix; ci >= cin_real returns 0.
+// Optional second K source (cin2 channels, one tap): get2(ci2, co), appended after the first.
 int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
-              const std::function<float(int, int, int)>& get, PackedConv* pc) {
+              const std::function<float(int, int, int)>& get, PackedConv* pc, int cin2 = 0,
+              const std::function<float(int, int)>& get2 = nullptr) {
   int cin = ((cin_real + chunk - 1) / chunk) * chunk;
   if (cin_real <= 48 && cin_real % 16 != 0) {  // first layer: 38 -> 48, single chunk
     cin = ((cin_real + 15) / 16) * 16;
     chunk = cin;
   }
-  int nkb = taps * cin / 16;
+  if (cin2 % chunk != 0) {
+    set_error("pack_conv: second source of %d channels is not a multiple of the chunk %d", cin2, chunk);
+    return TRACE_EINVAL;
+  }
+  int nkb = taps * cin / 16 + cin2 / 16;
   int kbpc = chunk / 16;
   std::vector<float> h((size_t)(cout / 16) * nkb * 64 * 4, 0.f);
   for (int ct = 0; ct < cout / 16; ++ct) {
     int kblk = 0;
+    auto put = [&](int c0, int tap, bool second) {
+      for (int kb = 0; kb < kbpc; ++kb, ++kblk)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int s = 0; s < 4; ++s) {
+            int ci = c0 + kb * 16 + (lane >> 4) * 4 + s;   // pass s of lane group kq = lane>>4
+            int co = ct * 16 + (lane & 15);
+            float v = second ? get2(ci, co) : (ci < cin_real ? get(tap, ci, co) : 0.f);
+            h[(((size_t)ct * nkb + kblk) * 64 + lane) * 4 + s] = v;
+          }
+    };
     for (int c0 = 0; c0 < cin; c0 += chunk)
-      for (int tap = 0; tap < taps; ++tap)
-        for (int kb = 0; kb < kbpc; ++kb, ++kblk)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int s = 0; s < 4; ++s) {
-              int ci = c0 + kb * 16 + (lane >> 4) * 4 + s;   // pass s of lane group kq = lane>>4
-              int co = ct * 16 + (lane & 15);
-              float v = ci < cin_real ? get(tap, ci, co) : 0.f;
-              h[(((size_t)ct * nkb + kblk) * 64 + lane) * 4 + s] = v;
-            }
+      for (int tap = 0; tap < taps; ++tap) put(c0, tap, false);
+    for (int c0 = 0; c0 < cin2; c0 += chunk) put(c0, 0, true);
   }
   float* d = nullptr;
   int rc = upload(u, h, &d);
@@ -284,6 +295,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
   pc->taps = taps;
   pc->chunk = chunk;
   pc->nkb = nkb;
+  pc->cin2 = cin2;
   return TRACE_OK;
 }
 
@@ -433,10 +445,7 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
     TRY(pack_conv(u, co_, co_, 5, 64, [=](int tap, int ci, int co) { return w2[((size_t)co * co_ + ci) * 5 + tap]; }, &b.c2f));
     // dgrad: K runs over (tap', co), output channel = ci, weight W[co][ci][4 - tap']
     TRY(pack_conv(u, co_, co_, 5, 64, [=](int tap, int k, int n) { return w2[((size_t)k * co_ + n) * 5 + (4 - tap)]; }, &b.c2b));
-    if (bi > 0)
-      TRY(pack_conv(u, co_, ci_, 5, 64, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b));
-    else
-      first_w1 = w1;
+    if (bi == 0) first_w1 = w1;
     TRY(upload_vec(u, b1, co_, &b.b1));
     TRY(upload_vec(u, g1, co_, &b.g1));
     TRY(upload_vec(u, be1, co_, &b.be1));
@@ -447,11 +456,15 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
       const float* wr = cur.take((int64_t)co_ * ci_);
       const float* br = cur.take(co_);
       TRY(pack_conv(u, ci_, co_, 1, 64, [=](int, int ci, int co) { return wr[(size_t)co * ci_ + ci]; }, &b.rf));
+      // input-VJP: the 1x1 residual conv's dgrad rides in the k5 dgrad as extra K (centre tap)
       if (bi > 0)
-        TRY(pack_conv(u, co_, ci_, 1, 64, [=](int, int k, int n) { return wr[(size_t)k * ci_ + n]; }, &b.rb));
+        TRY(pack_conv(u, co_, ci_, 5, 64, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b,
+                      co_, [=](int k, int n) { return wr[(size_t)k * ci_ + n]; }));
       else
         first_wr = wr;
       TRY(upload_vec(u, br, co_, &b.br));
+    } else if (bi > 0) {
+      TRY(pack_conv(u, co_, ci_, 5, 64, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b));
     }
     u->blocks.push_back(b);
   }
@@ -680,8 +693,39 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.out_coff = out.coff;
   a.cout = w.cout;
   a.rows = rows;
-  a.alg_macs_per_pos = (double)w.cout * w.cin_real * w.taps;
+  a.alg_macs_per_pos = (double)w.cout * w.cin_real * w.taps + (double)w.cout * w.cin2;
+  a.cin2 = w.cin2;     // the caller must point in2 at the second source (set_in2)
   return a;
+}
+
+void set_in2(ConvArgs& a, const View& v) {
+  a.in2 = v.p;
+  a.in2_tstride = v.tstride();
+  a.in2_coff = v.coff;
+}
+
+// GroupNorm + Mish backward fused into a dgrad epilogue: `dy` receives d/dy of the layer whose
+// saved pre-norm output is y (C channels), `raw` (optional) the un-normed gradient itself.
+void set_gnb(ConvArgs& a, const float* y, const float* stats, const float* gamma, const float* beta,
+             int C, const View& dy, const View* raw) {
+  a.gnb = 1;
+  a.gb_cmax = C;
+  a.gb_y = y;
+  a.gb_stats = stats;
+  a.gb_gamma = gamma;
+  a.gb_beta = beta;
+  a.gb_cg = C / 8;
+  a.gb_c = C;
+  if (raw) {
+    a.out_raw = raw->p;
+    a.raw_tstride = raw->tstride();
+    a.raw_coff = raw->coff;
+  } else {
+    a.out_raw = nullptr;
+  }
+  a.out = dy.p;
+  a.out_tstride = dy.tstride();
+  a.out_coff = dy.coff;
 }
 
 void set_res(ConvArgs& a, const View& r) {
@@ -848,23 +892,42 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
   float *T1 = buf(u->b_T1), *T2 = buf(u->b_T2), *G0 = buf(u->b_G0), *G1 = buf(u->b_G1);
   View dcat1{buf(u->b_dcat1), 2 * d1, 0, H / 2}, dcat2{buf(u->b_dcat2), 2 * d2, 0, H / 4};
 
-  // backward of one residual block: dout -> dx (+ optional extra addend), see DESIGN.md
-  auto block_bwd = [&](int i, const View& dout, const View& dx, const View* extra) -> int {
+  // GroupNorm+Mish backward is fused into the epilogue of whichever dgrad conv PRODUCES the
+  // gradient (set_gnb); only the very first one (after the head) runs as its own kernel.
+  //
+  // Backward of one residual block.  On entry T1 already holds gnb(dout; y2_i) (written by the
+  // producer of dout).  `next` = index of the block whose output gradient dx is (its y2 drives the
+  // fused norm-backward of the last conv), or -1 for none; next_c = channels of that norm.
+  //   T2 = gnb(dgrad_c2(T1); y1_i)
+  //   dx = dgrad_c1(T2) [+ dgrad_res(dout) as extra K | + dout] [+ extra];  T1 = gnb(dx; y2_next)
+  auto block_bwd = [&](int i, const View& dout, const View& dx, const View* extra, int next) -> int {
     const Block& b = u->blocks[i];
     View t1{T1, b.cout, 0, b.L}, t2{T2, b.cout, 0, b.L};
-    RUN(run_gn_bwd(dout, buf(u->b_y2[i]), buf(u->b_s2[i]), b.g2, b.be2, T1, b.cout, b.L, rows, st));
-    RUN(run_conv(K_CONV5, b.L, conv_args(t1, b.c2b, nullptr, t2, rows), st));
-    RUN(run_gn_bwd(t2, buf(u->b_y1[i]), buf(u->b_s1[i]), b.g1, b.be1, T1, b.cout, b.L, rows, st));
-    ConvArgs a = conv_args(t1, b.c1b, nullptr, dx, rows);
-    if (!b.has_res) set_res(a, dout);
-    if (extra) set_res2(a, *extra);
-    RUN(run_conv(K_CONV5, b.L, a, st));
-    if (b.has_res) {
-      ConvArgs ar = conv_args(dout, b.rb, nullptr, dx, rows);
-      set_res(ar, dx);
-      RUN(run_conv(K_CONV1, b.L, ar, st));
+    {
+      ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
+      set_gnb(a, buf(u->b_y1[i]), buf(u->b_s1[i]), b.g1, b.be1, b.cout, t2, nullptr);
+      RUN(run_conv(K_CONV5, b.L, a, st));
     }
+    ConvArgs a = conv_args(t2, b.c1b, nullptr, dx, rows);
+    if (b.has_res) set_in2(a, dout); else set_res(a, dout);
+    if (extra) set_res2(a, *extra);
+    if (next >= 0) {
+      const Block& nb = u->blocks[next];
+      View nt1{T1, nb.cout, 0, nb.L};
+      set_gnb(a, buf(u->b_y2[next]), buf(u->b_s2[next]), nb.g2, nb.be2, nb.cout, nt1, &dx);
+    }
+    RUN(run_conv(K_CONV5, b.L, a, st));
     return TRACE_OK;
+  };
+  // up/down-sampling dgrad whose output is the dout of block `next`
+  auto resample_bwd = [&](ConvKind kind, int L_out, const View& in, const PackedConv& w, const View& dx,
+                          const View* res, int next) -> int {
+    ConvArgs a = conv_args(in, w, nullptr, dx, rows);
+    if (res) set_res(a, *res);
+    const Block& nb = u->blocks[next];
+    View nt1{T1, nb.cout, 0, nb.L};
+    set_gnb(a, buf(u->b_y2[next]), buf(u->b_s2[next]), nb.g2, nb.be2, nb.cout, nt1, &dx);
+    return run_conv(kind, L_out, a, st);
   };
 
   // head + final block
@@ -877,44 +940,56 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
     RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, T1, d0, H, rows, st));
     RUN(run_conv(K_CONV5, H, conv_args(t1, u->final_b, nullptr, g1, rows), st));
   }
-  // up1 (ConvT d0: L/2 -> L)
-  RUN(run_conv(K_UP_B, H / 2, conv_args(View{G1, d0, 0, H}, u->up_b[1], nullptr, View{G0, d0, 0, H / 2}, rows), st));
-  RUN(block_bwd(11, View{G0, d0, 0, H / 2}, View{G1, d0, 0, H / 2}, nullptr));
-  RUN(block_bwd(10, View{G1, d0, 0, H / 2}, dcat1, nullptr));
-  // up0 (ConvT d1: L/4 -> L/2) reads the first half of dcat1
-  RUN(run_conv(K_UP_B, H / 4, conv_args(View{dcat1.p, dcat1.ctot, 0, dcat1.L}, u->up_b[0], nullptr,
-                                         View{G0, d1, 0, H / 4}, rows), st));
-  RUN(block_bwd(9, View{G0, d1, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr));
-  RUN(block_bwd(8, View{G1, d1, 0, H / 4}, dcat2, nullptr));
+  // up1 (ConvT d0: L/2 -> L): its dgrad output is dout of block 11
+  RUN(resample_bwd(K_UP_B, H / 2, View{G1, d0, 0, H}, u->up_b[1], View{G0, d0, 0, H / 2}, nullptr, 11));
+  RUN(block_bwd(11, View{G0, d0, 0, H / 2}, View{G1, d0, 0, H / 2}, nullptr, 10));
+  RUN(block_bwd(10, View{G1, d0, 0, H / 2}, dcat1, nullptr, -1));
+  // up0 (ConvT d1: L/4 -> L/2) reads the first half of dcat1; output = dout of block 9
+  RUN(resample_bwd(K_UP_B, H / 4, View{dcat1.p, dcat1.ctot, 0, dcat1.L}, u->up_b[0],
+                   View{G0, d1, 0, H / 4}, nullptr, 9));
+  RUN(block_bwd(9, View{G0, d1, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr, 8));
+  // block 8 writes dcat2 (2*d2 channels); only its first half is dout of mid2 (block 7)
+  {
+    const Block& b = u->blocks[8];
+    View t1{T1, b.cout, 0, b.L}, t2{T2, b.cout, 0, b.L};
+    ConvArgs a2 = conv_args(t1, b.c2b, nullptr, t2, rows);
+    set_gnb(a2, buf(u->b_y1[8]), buf(u->b_s1[8]), b.g1, b.be1, b.cout, t2, nullptr);
+    RUN(run_conv(K_CONV5, b.L, a2, st));
+    ConvArgs a = conv_args(t2, b.c1b, nullptr, dcat2, rows);
+    set_in2(a, View{G1, d1, 0, H / 4});
+    const Block& nb = u->blocks[7];
+    View nt1{T1, nb.cout, 0, nb.L};
+    set_gnb(a, buf(u->b_y2[7]), buf(u->b_s2[7]), nb.g2, nb.be2, nb.cout, nt1, &dcat2);
+    RUN(run_conv(K_CONV5, b.L, a, st));
+  }
   // mid2: dout = dcat2[0:d2]
-  RUN(block_bwd(7, View{dcat2.p, dcat2.ctot, 0, dcat2.L}, View{G0, d2, 0, H / 4}, nullptr));
+  RUN(block_bwd(7, View{dcat2.p, dcat2.ctot, 0, dcat2.L}, View{G0, d2, 0, H / 4}, nullptr, 6));
   // mid1: + skip gradient dcat2[d2:2*d2]
   {
     View skip{dcat2.p, dcat2.ctot, d2, dcat2.L};
-    RUN(block_bwd(6, View{G0, d2, 0, H / 4}, View{G1, d2, 0, H / 4}, &skip));
+    RUN(block_bwd(6, View{G0, d2, 0, H / 4}, View{G1, d2, 0, H / 4}, &skip, 5));
   }
-  RUN(block_bwd(5, View{G1, d2, 0, H / 4}, View{G0, d2, 0, H / 4}, nullptr));
-  RUN(block_bwd(4, View{G0, d2, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr));
-  // down1 (Conv k3 s2 d1: L/2 -> L/4) + skip gradient dcat1[d1:2*d1]
+  RUN(block_bwd(5, View{G1, d2, 0, H / 4}, View{G0, d2, 0, H / 4}, nullptr, 4));
+  RUN(block_bwd(4, View{G0, d2, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr, -1));
+  // down1 (Conv k3 s2 d1: L/2 -> L/4) + skip gradient dcat1[d1:2*d1]; output = dout of block 3
   {
-    ConvArgs a = conv_args(View{G1, d1, 0, H / 4}, u->down_b[1], nullptr, View{G0, d1, 0, H / 2}, rows);
-    set_res(a, View{dcat1.p, dcat1.ctot, d1, dcat1.L});
-    RUN(run_conv(K_DOWN_B, H / 2, a, st));
+    View skip{dcat1.p, dcat1.ctot, d1, dcat1.L};
+    RUN(resample_bwd(K_DOWN_B, H / 2, View{G1, d1, 0, H / 4}, u->down_b[1], View{G0, d1, 0, H / 2}, &skip, 3));
   }
-  RUN(block_bwd(3, View{G0, d1, 0, H / 2}, View{G1, d1, 0, H / 2}, nullptr));
-  RUN(block_bwd(2, View{G1, d1, 0, H / 2}, View{G0, d0, 0, H / 2}, nullptr));
+  RUN(block_bwd(3, View{G0, d1, 0, H / 2}, View{G1, d1, 0, H / 2}, nullptr, 2));
+  RUN(block_bwd(2, View{G1, d1, 0, H / 2}, View{G0, d0, 0, H / 2}, nullptr, -1));
   // down0 (Conv k3 s2 d0: L -> L/2); the level-0 skip is never consumed (temporal.py:129,134)
-  RUN(run_conv(K_DOWN_B, H, conv_args(View{G0, d0, 0, H / 2}, u->down_b[0], nullptr, View{G1, d0, 0, H}, rows), st));
-  RUN(block_bwd(1, View{G1, d0, 0, H}, View{G0, d0, 0, H}, nullptr));
+  RUN(resample_bwd(K_DOWN_B, H, View{G0, d0, 0, H / 2}, u->down_b[0], View{G1, d0, 0, H}, nullptr, 1));
+  RUN(block_bwd(1, View{G1, d0, 0, H}, View{G0, d0, 0, H}, nullptr, 0));
   // first block: only input channels [4,5] are needed (tbsim/models/trace.py:674-676)
   {
     const Block& b = u->blocks[0];
-    View dout{G0, d0, 0, H};
-    RUN(run_gn_bwd(dout, buf(u->b_y2[0]), buf(u->b_s2[0]), b.g2, b.be2, T1, b.cout, b.L, rows, st));
-    RUN(run_conv(K_CONV5, b.L, conv_args(View{T1, d0, 0, H}, b.c2b, nullptr, View{T2, d0, 0, H}, rows), st));
-    RUN(run_gn_bwd(View{T2, d0, 0, H}, buf(u->b_y1[0]), buf(u->b_s1[0]), b.g1, b.be1, T1, b.cout, b.L, rows, st));
+    View t1{T1, d0, 0, H}, t2{T2, d0, 0, H};
+    ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
+    set_gnb(a, buf(u->b_y1[0]), buf(u->b_s1[0]), b.g1, b.be1, b.cout, t2, nullptr);
+    RUN(run_conv(K_CONV5, b.L, a, st));
     int n = rows * H;
-    hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, T1, G0,
+    hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, T2, G0,
                        u->first_wsel, u->first_rsel, grad_x, d0, H, rows);
     RUN(launch_status("first_dgrad_kernel"));
   }
