@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libtrace_hip.so")
+# TRACE_HIP_LIB: diagnostic builds only (e.g. the time-stamped library of scripts/stamps.py)
+LIB_PATH = os.environ.get("TRACE_HIP_LIB") or os.path.join(_HERE, "lib", "libtrace_hip.so")
 
 
 class TraceHipError(RuntimeError):

@@ -80,7 +80,70 @@ struct ConvArgs {
   float* out_raw;      // or null
   int raw_tstride;
   int raw_coff;
+  unsigned long long* dbg;   // diagnostic builds only (TRACE_CONV_STAMPS): 16 time stamps per workgroup
 };
+
+#ifdef TRACE_CONV_STAMPS
+#define TRACE_STAMP(i)                                                                \
+  do {                                                                                \
+    if (a.dbg && threadIdx.x == 0)                                                    \
+      a.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime();            \
+  } while (0)
+unsigned long long* stamp_buffer_for_next_launch();
+#else
+#define TRACE_STAMP(i) do { } while (0)
+#endif
+
+// Sum over the cg neighbouring lanes of a GroupNorm group (cg a power of two <= 64), for NP
+// independent values at once.  Inside a row of 16 lanes the butterfly runs on DPP modifiers (pure
+// VALU: quad_perm for xor 1 / 2, row_half_mirror and row_mirror for the 8- and 16-lane steps, which
+// act as xor 4 / 8 once the lanes of a quad / half-row agree); rows are combined through
+// v_readlane.  A ds_bpermute round trip per step costs ~350 cycles on the loaded LDS (measured
+// with in-kernel stamps), ten dependent ones per statistic.
+__device__ __forceinline__ float dpp_add(float v, int ctrl_tag) {
+  const int x = __builtin_bit_cast(int, v);
+  int y;
+  switch (ctrl_tag) {
+    case 1: y = __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, false); break;    // quad_perm [1,0,3,2]
+    case 2: y = __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, false); break;    // quad_perm [2,3,0,1]
+    case 4: y = __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, false); break;   // row_half_mirror
+    default: y = __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, false); break;  // row_mirror
+  }
+  return v + __builtin_bit_cast(float, y);
+}
+
+template <int NP>
+__device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
+  if (cg > 1) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) v[j] = dpp_add(v[j], 1);
+  }
+  if (cg > 2) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) v[j] = dpp_add(v[j], 2);
+  }
+  if (cg > 4) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) v[j] = dpp_add(v[j], 4);
+  }
+  if (cg > 8) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) v[j] = dpp_add(v[j], 8);
+  }
+  if (cg > 16) {
+    const bool upper = (threadIdx.x & 32) != 0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int x = __builtin_bit_cast(int, v[j]);
+      const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+      const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+      const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+      const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+      const float lo = r0 + r1, hi = r2 + r3;
+      v[j] = cg > 32 ? lo + hi : (upper ? hi : lo);
+    }
+  }
+}
 
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
 struct ConvGeom {
@@ -115,8 +178,24 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int traj0 = blockIdx.x * TB;
-  const int co0 = blockIdx.y * 64;
+  // Workgroup id -> (row block, column tile).  Consecutive ids go round-robin over the 8 XCDs
+  // (id % 8), each with its own L2, so the ncol column tiles of one row block -- which all stage
+  // the same activations -- are given ids of the same residue, 8 apart: they run at the same time
+  // behind the same L2 and the input comes from HBM once instead of ncol times.
+  const int ncol = a.cout >> 6;
+  const int bid = blockIdx.x;
+  const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
+  const int ct = (bid >> 3) % ncol;
+  if (rb * TB >= a.rows) return;               // padding ids of the last group of 8 row blocks
+  const int traj0 = rb * TB;
+  const int co0 = ct * 64;
+  TRACE_STAMP(0);
+#ifdef TRACE_CONV_STAMPS
+  if (a.dbg && threadIdx.x == 0) {
+    a.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+    a.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+  }
+#endif
 
   // ---- staging: thread handles float4 #(tid + 256 j) of the chunk -------------------------
   // Buffer loads with a 32-bit byte offset: the descriptor's range check returns 0 for
@@ -173,9 +252,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
 
   stage_load(0);
   // halo / zero-stuffing positions are written once; data positions are the same for every chunk
+  if constexpr (UP == 1 && IN_STRIDE == 1 && TAPS == 1) {
+    // 1x1 conv: no halo, every position is overwritten by stage_write
+  } else if constexpr (UP == 1 && IN_STRIDE == 1) {
+    // every data position is overwritten by stage_write: only the TAPS-1 halo positions per
+    // trajectory need zeros
+    constexpr int HALO = LP - L_IN;                     // = TAPS - 1, PADL of them in front
+    constexpr int Q = CHS / 4;
+    for (int i = tid; i < TB * HALO * Q; i += 256) {
+      const int tr = i / (HALO * Q);
+      const int r = i - tr * (HALO * Q);
+      const int h = r / Q;
+      const int pos = tr * LP + (h < PADL ? h : L_IN + h);
+      reinterpret_cast<f32x4*>(lds)[pos * Q + (r - h * Q)] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
 #pragma unroll 2
-  for (int i = tid; i < CHS * S / 4; i += 256)
-    reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < CHS * S / 4; i += 256)
+      reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   // LDS image is [position][channel]; lane (row = lane&15, kq = lane>>4) reads the 4 channels
   // 16m + 4kq .. +3 of its output row's input position with one ds_read_b128, and feeds element
@@ -192,14 +287,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const f32x4* wp = a.wp + ((size_t)(blockIdx.y * 4 + wave) * a.nkb) * 64 + lane;
+  const f32x4* wp = a.wp + ((size_t)(ct * 4 + wave) * a.nkb) * 64 + lane;
   f32x4 bnext = *wp;
   f32x4 bnext2 = a.nkb > 1 ? wp[64] : bnext;
   int kdone = 0;
 
+  TRACE_STAMP(14);
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();            // previous chunk fully consumed (and zero fill done)
     stage_write();
+    if (ch == 0) TRACE_STAMP(15);
     if (ch + 1 < nch) stage_load(ch + 1);       // in flight during this chunk's K loop
     __syncthreads();
 
@@ -207,6 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     // values of 4 MFMA passes; the read for the NEXT k-block is issued right after the last pass
     // that consumes the register, i.e. 13 MFMAs (>400 cycles) ahead of its first use.
     // Chunks of the second source contribute at the centre tap only.
+    if (ch == 0) TRACE_STAMP(1);
     const bool second = ch >= nch1;
     int kk = second ? PADL * KBPC : 0;
     const int kk_end = second ? (PADL + 1) * KBPC : NKK;
@@ -240,6 +338,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
       kb = kb2;
       tap = tap2;
     }
+    if (ch < 4) TRACE_STAMP(2 + ch);
   }
 
   // ---- epilogue --------------------------------------------------------------------------
@@ -314,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     }
   }
   __syncthreads();
+  TRACE_STAMP(10);
 
   typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
   if (a.gnb) {
@@ -335,73 +435,78 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
       }
       *reinterpret_cast<f32x4*>(lds + f) = y;
     }
-    if (!normed) return;                       // uniform per workgroup
+    if (!normed) { TRACE_STAMP(11); return; }  // uniform per workgroup
     __syncthreads();
-    // G2 (rows): thread = one (trajectory, channel) row, lanes = channels
+    // G2 (rows): thread = one (trajectory, channel) row per pass, lanes = channels
     {
       constexpr int NP = TB / 4;
       const int c = lane, co = co0 + c;
       const int cg = a.gb_cg, cgs = __builtin_ctz(cg);
       const float gam = a.gb_gamma[co], bet = a.gb_beta[co];
       const float inv_n = 1.f / (float)(cg * L_OUT);
+      float gz[NP][L_OUT], xh[NP][L_OUT], s1[NP], s2[NP], rs[NP];
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
         const int tr = wave + 4 * j;
         const int tg = min(traj0 + tr, a.rows - 1);
-        float* row = lds + (tr * 64 + c) * L_OUT;
+        const float* row = lds + (tr * 64 + c) * L_OUT;
         const float* yrow = a.gb_y + ((size_t)tg * a.gb_c + co) * L_OUT;
         const float* stp = a.gb_stats + ((size_t)tg * (a.gb_c >> cgs) + (co >> cgs)) * 2;
         const float mean = stp[0], rstd = stp[1];
-        float gz[L_OUT], xh[L_OUT];
+        rs[j] = rstd;
         if constexpr (L_OUT % 4 == 0) {
 #pragma unroll
           for (int i = 0; i < L_OUT / 4; ++i) {
             const f32x4 t = reinterpret_cast<const f32x4*>(row)[i];
             const f32x4 w = reinterpret_cast<const f32x4*>(yrow)[i];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { gz[4 * i + e] = t[e]; xh[4 * i + e] = w[e]; }
+            for (int e = 0; e < 4; ++e) { gz[j][4 * i + e] = t[e]; xh[j][4 * i + e] = w[e]; }
           }
         } else if constexpr (L_OUT % 2 == 0) {
 #pragma unroll
           for (int i = 0; i < L_OUT / 2; ++i) {
             const float2 t = reinterpret_cast<const float2*>(row)[i];
             const float2 w = reinterpret_cast<const float2*>(yrow)[i];
-            gz[2 * i] = t.x; gz[2 * i + 1] = t.y; xh[2 * i] = w.x; xh[2 * i + 1] = w.y;
+            gz[j][2 * i] = t.x; gz[j][2 * i + 1] = t.y; xh[j][2 * i] = w.x; xh[j][2 * i + 1] = w.y;
           }
         } else {
 #pragma unroll
-          for (int i = 0; i < L_OUT; ++i) { gz[i] = row[i]; xh[i] = yrow[i]; }
+          for (int i = 0; i < L_OUT; ++i) { gz[j][i] = row[i]; xh[j][i] = yrow[i]; }
         }
-        float s1 = 0.f, s2 = 0.f;
+        float t1 = 0.f, t2 = 0.f;
 #pragma unroll
         for (int i = 0; i < L_OUT; ++i) {
-          const float x = (xh[i] - mean) * rstd;
+          const float x = (xh[j][i] - mean) * rstd;
           const float z = fmaf(x, gam, bet);
-          const float d = gz[i] * mish_grad_fast_f(z) * gam;
-          gz[i] = d;
-          xh[i] = x;
-          s1 += d;
-          s2 = fmaf(d, x, s2);
+          const float d = gz[j][i] * mish_grad_fast_f(z) * gam;
+          gz[j][i] = d;
+          xh[j][i] = x;
+          t1 += d;
+          t2 = fmaf(d, x, t2);
         }
-        for (int m = 1; m < cg; m <<= 1) {
-          s1 += __shfl_xor(s1, m);
-          s2 += __shfl_xor(s2, m);
-        }
-        s1 *= inv_n;
-        s2 *= inv_n;
+        s1[j] = t1;
+        s2[j] = t2;
+      }
+      group_sum<NP>(s1, cg);
+      group_sum<NP>(s2, cg);
 #pragma unroll
-        for (int i = 0; i < L_OUT; ++i) gz[i] = rstd * (gz[i] - s1 - xh[i] * s2);
+      for (int j = 0; j < NP; ++j) {
+        float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
+        const float m1 = s1[j] * inv_n, m2 = s2[j] * inv_n, rstd = rs[j];
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) gz[j][i] = rstd * (gz[j][i] - m1 - xh[j][i] * m2);
         if constexpr (L_OUT % 4 == 0) {
 #pragma unroll
           for (int i = 0; i < L_OUT / 4; ++i)
-            reinterpret_cast<f32x4*>(row)[i] = f32x4{gz[4 * i], gz[4 * i + 1], gz[4 * i + 2], gz[4 * i + 3]};
+            reinterpret_cast<f32x4*>(row)[i] =
+                f32x4{gz[j][4 * i], gz[j][4 * i + 1], gz[j][4 * i + 2], gz[j][4 * i + 3]};
         } else if constexpr (L_OUT % 2 == 0) {
 #pragma unroll
           for (int i = 0; i < L_OUT / 2; ++i)
-            reinterpret_cast<float2*>(row)[i] = float2{gz[2 * i], gz[2 * i + 1]};
+            reinterpret_cast<float2*>(row)[i] = float2{gz[j][2 * i], gz[j][2 * i + 1]};
         } else {
 #pragma unroll
-          for (int i = 0; i < L_OUT; ++i) row[i] = gz[i];
+          for (int i = 0; i < L_OUT; ++i) row[i] = gz[j][i];
         }
       }
     }
@@ -417,6 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro,
                                              flat_off(k, a.out_tstride, a.out_coff, rem), 0, 0);
     }
+    TRACE_STAMP(11);
     return;
   }
 
@@ -430,13 +536,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     const float bet = a.gn ? a.beta[co] : 0.f;
     const float ptv = a.pc ? a.pt[co] : 0.f;
     const int cg = a.gn ? a.cg : 1;
+    float add[NP], rmean[NP], m2[NP], gs[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const int tr = wave + 4 * j;
-      const int tg = min(traj0 + tr, a.rows - 1);
-      float scale = 1.f, shift = 0.f;
-      if (a.gn) {
-        const float* row = lds + (tr * 64 + c) * L_OUT;
+      const int tg = min(traj0 + wave + 4 * j, a.rows - 1);
+      add[j] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
+      rmean[j] = 0.f;
+      m2[j] = 0.f;
+    }
+    if (a.gn) {
+      // exact two-level moments: row mean / centred sum of squares per (trajectory, channel)
+      // row, then Chan's combination over the channels of the group
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
         float v[L_OUT];
         if constexpr (L_OUT % 4 == 0) {
 #pragma unroll
@@ -454,27 +567,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < L_OUT; ++i) v[i] = row[i];
         }
-        // exact two-level moments: row mean / centred sum of squares, then Chan's combination
-        float s = 0.f;
+        float sacc = 0.f;
 #pragma unroll
-        for (int i = 0; i < L_OUT; ++i) s += v[i];
-        const float rmean = s * (1.f / (float)L_OUT);
-        float m2 = 0.f;
+        for (int i = 0; i < L_OUT; ++i) sacc += v[i];
+        const float rm = sacc * (1.f / (float)L_OUT);
+        float q = 0.f;
 #pragma unroll
         for (int i = 0; i < L_OUT; ++i) {
-          const float d = v[i] - rmean;
-          m2 = fmaf(d, d, m2);
+          const float d = v[i] - rm;
+          q = fmaf(d, d, q);
         }
-        float gs = rmean;
-        for (int m = 1; m < cg; m <<= 1) gs += __shfl_xor(gs, m);
-        const float mean = gs / (float)cg;
-        const float dm = rmean - mean;
-        float gv = fmaf(dm * dm, (float)L_OUT, m2);
-        for (int m = 1; m < cg; m <<= 1) gv += __shfl_xor(gv, m);
-        const float var = gv / (float)(cg * L_OUT);
+        rmean[j] = rm;
+        m2[j] = q;
+        gs[j] = rm;
+      }
+      TRACE_STAMP(6);
+      group_sum<NP>(gs, cg);
+      float gv[NP];
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        gs[j] = gs[j] / (float)cg;                       // group mean
+        const float dm = rmean[j] - gs[j];
+        gv[j] = fmaf(dm * dm, (float)L_OUT, m2[j]);
+      }
+      group_sum<NP>(gv, cg);
+      TRACE_STAMP(7);
+#pragma unroll
+      for (int j = 0; j < NP; ++j) {
+        const int tr = wave + 4 * j;
+        const float mean = gs[j];
+        const float var = gv[j] / (float)(cg * L_OUT);
         const float rstd = 1.f / sqrtf(var + 1e-5f);
-        scale = rstd * gam;
-        shift = bet - mean * scale;
+        const float scale = rstd * gam;
+        tab[tr * 64 + c] = f32x4{scale, bet - mean * scale, add[j], 0.f};
         if (a.stats && (c & (cg - 1)) == 0 && traj0 + tr < a.rows) {
           const int cgs = __builtin_ctz(cg);
           const size_t si = ((size_t)(traj0 + tr) * (a.cout >> cgs) + (co >> cgs)) * 2;
@@ -482,12 +607,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
           a.stats[si + 1] = rstd;
         }
       }
-      const float add =
-          a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
-      tab[tr * 64 + c] = f32x4{scale, shift, add, 0.f};
+    } else {
+#pragma unroll
+      for (int j = 0; j < NP; ++j) tab[(wave + 4 * j) * 64 + c] = f32x4{1.f, 0.f, add[j], 0.f};
     }
+    TRACE_STAMP(8);
     __syncthreads();
   }
+  TRACE_STAMP(9);
 
   // E2: flat pass -- normalise / activate / add / store, 4 consecutive outputs per access
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
@@ -525,6 +652,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     y += rv[k];
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y), ro, oo, 0, 0);
   }
+  TRACE_STAMP(11);
 }
 
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
@@ -575,7 +703,11 @@ int launch_conv(const ConvArgs& a_in, hipStream_t st) {
         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr_set = true;
   }
-  dim3 grid((a.rows + TB - 1) / TB, a.cout / 64);
+  const int nrb = (a.rows + TB - 1) / TB;
+  dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 64));
+#ifdef TRACE_CONV_STAMPS
+  a.dbg = stamp_buffer_for_next_launch();
+#endif
   const bool prof = prof_active();
   if (prof) prof_pre(st);
   hipLaunchKernelGGL((conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>), grid, dim3(256),

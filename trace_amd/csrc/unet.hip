@@ -39,6 +39,25 @@ void prof_post(hipStream_t st, double flops) {
   ++g_prof.n;
 }
 
+#ifdef TRACE_CONV_STAMPS
+// Diagnostic build only (scripts/stamps.py): the conv launch number `g_stamp_target` after
+// trace_debug_stamps() writes 16 s_memtime stamps per workgroup into the given device buffer.
+namespace {
+unsigned long long* g_stamp_buf = nullptr;
+int g_stamp_target = -1, g_stamp_count = 0;
+}  // namespace
+unsigned long long* stamp_buffer_for_next_launch() {
+  return (g_stamp_count++ == g_stamp_target) ? g_stamp_buf : nullptr;
+}
+}  // namespace trace
+extern "C" void trace_debug_stamps(void* buf, int launch_index) {
+  trace::g_stamp_buf = reinterpret_cast<unsigned long long*>(buf);
+  trace::g_stamp_target = launch_index;
+  trace::g_stamp_count = 0;
+}
+namespace trace {
+#endif
+
 // --------------------------------------------------------------------------------------
 // small kernels
 // --------------------------------------------------------------------------------------
