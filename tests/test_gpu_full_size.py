@@ -134,3 +134,34 @@ def test_dense_scene_agent_collision_step_matches_the_oracle():
     assert rel < 1e-4, rel
     gl = out["predictions"]["guide_losses"]["agent_collision_scene_000_00"].cpu()
     assert torch.allclose(gl, per["agent_collision_scene_000_00"], rtol=5e-3, atol=1e-5)
+
+
+def test_image_only_batch_runs_through_the_map_encoder():
+    """Row A0 end to end: a batch WITHOUT precomputed map features goes image -> ResNet-18 encoder
+    (trace_amd/map_encoder.py, MIOpen) -> map_grid_feat -> sampler, and agrees with feeding the
+    same encoder's CPU output as `map_grid_feat` (parity of the encoder itself is unpinned, see
+    its docstring)."""
+    from trace_amd.map_encoder import MapEncoder, random_map_encoder_state_dict
+    from trace_amd.policy import DiffuserTrafficModel
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 0)
+    sd.update(random_map_encoder_state_dict(cfg.image_shape[0], cfg.map_grid_feature_dim,
+                                            tuple(cfg.image_shape[1:]), seed=4))
+    aps, N = [3, 2], 2
+    batch = syn.make_batch(cfg, aps, seed=1, extent=(0.9, 0.7, 1.75), dense=True)
+    img = batch["image"]
+    enc_cpu = MapEncoder(sd, "cpu")
+    _, grid = enc_cpu(img)
+    _, grid_nc = enc_cpu(torch.ones_like(img) * cfg.conditioning_drop_fill)
+    _, grid_gpu = MapEncoder(sd, DEV)(img)
+    assert float((grid_gpu.cpu() - grid).abs().max()) < 1e-3 * float(grid.abs().max())
+    init, steps = syn.make_noise(cfg, sum(aps), N, seed=3)
+    model = DiffuserTrafficModel(cfg, sd, DEV)
+    assert model.sampler.map_encoder is not None
+    b_img = {k: v for k, v in batch.items() if not k.startswith("map_grid_feat")}
+    b_feat = dict(b_img, map_grid_feat=grid, map_grid_feat_non_cond=grid_nc)
+    kw = dict(num_samp=N, class_free_guide_w=0.5, noise_init=init, noise_steps=steps, n_steps=4)
+    a = model.sampler(b_img, **kw)["pred_traj_scaled"].cpu()
+    b = model.sampler(b_feat, **kw)["pred_traj_scaled"].cpu()
+    assert torch.isfinite(a).all()
+    assert float(((a - b).abs() / (1.0 + b.abs())).max()) < 5e-3

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from .config import ModelConfig
+from .map_encoder import MapEncoder, has_map_encoder
 from .sampler import TraceSampler
 from .weights import extract_policy_state_dict, random_state_dict
 
@@ -160,6 +161,9 @@ class DiffuserTrafficModel(object):
                  map_encoder=None):
         self.algo_config = model_config
         self.device = torch.device(device)
+        if map_encoder is None and has_map_encoder(state_dict):
+            # the checkpoint carries the ResNet-18 map encoder (trace.py:103-113): image -> grid
+            map_encoder = MapEncoder(state_dict, device)
         self.sampler = TraceSampler(model_config, state_dict, device, map_encoder=map_encoder)
         if guidance_config is not None:
             self.set_guidance(guidance_config)
