@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--scenes", type=int, default=None, help="override scenes per GPU (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step loop as one hipGraph (captured during warm-up); pays off on "
+                         "launch-bound small batches such as cfg1")
     ap.add_argument("--host-inputs", action="store_true",
                     help="keep the observation batch in host memory (PCIe-inclusive rate; not the headline)")
     args = ap.parse_args()
@@ -128,7 +131,7 @@ def main():
     gen = torch.Generator(device=device).manual_seed(7 + rank)
 
     def one_step(i):
-        action, info = policy.get_action(batch, step_index=i, generator=gen)
+        action, info = policy.get_action(batch, step_index=i, generator=gen, use_graph=args.graph)
         scores = info.get("guide_scores")
         if scores is None:
             scores = torch.zeros(B, N, device=device)
@@ -196,7 +199,7 @@ def main():
             "config": {"workload": args.workload, "agents_per_gpu": B, "samples_per_agent": N,
                        "trajectories_per_gpu": M, "ddpm_steps": cfg.n_diffusion_steps,
                        "horizon": cfg.horizon, "class_free_guide_w": wl["w"],
-                       "guidance": wl["guide"], "guide_clean": wl["clean"],
+                       "guidance": wl["guide"], "guide_clean": wl["clean"], "hip_graph": bool(args.graph),
                        "parallelism": "scenes sharded over %d GPU(s), all-gather of scores/plans" % world},
         }
         if roofline is not None:

@@ -210,6 +210,33 @@ class GuidancePlan:
         self.sel_scene_id = sid.to(device)
         self.sel_num_scenes = int(sid.max().item()) + 1 if B > 0 else 0
 
+    # -- hipGraph replay support ------------------------------------------------------ #
+    _SHARED = ("extent", "world_from_agent", "raster_from_agent", "drivable", "scene_start",
+               "scene_size", "sel_valid", "sel_scene_level", "sel_scene_id")
+
+    def signature(self):
+        """Hashable description of everything a captured launch sequence depends on besides the
+        CONTENTS of the device tables: layer kinds / static keys / masks and table shapes."""
+        layers = tuple((ly["kind"], ly["key"], tuple(ly["mask"].tolist()),
+                        tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in ly["dev"].items())))
+                       for ly in self.layers)
+        shared = tuple((n, None if getattr(self, n) is None else tuple(getattr(self, n).shape))
+                       for n in self._SHARED)
+        return (self.B, self.N, self.T, layers, shared, tuple(i.key_name for i in self.instances),
+                self.sel_num_scenes)
+
+    def load_tables_from(self, other):
+        """Copies the device tables of `other` (same signature) into this plan's tensors, whose
+        addresses a captured graph holds."""
+        assert self.signature() == other.signature(), "guidance structure changed: re-capture"
+        for n in self._SHARED:
+            t = getattr(self, n)
+            if t is not None:
+                t.copy_(getattr(other, n))
+        for a, b in zip(self.layers, other.layers):
+            for k, v in a["dev"].items():
+                v.copy_(b["dev"][k])
+
     # -- config -> kernel items ------------------------------------------------------ #
     def _make_items(self, gc, mask, nm, scale, cpu, global_t):
         T = self.T

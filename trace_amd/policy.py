@@ -202,7 +202,8 @@ class DiffuserTrafficModel(object):
                    guide_as_filter_only=False, guide_with_gt=False, guide_clean=False, **kwargs):
         step_index = kwargs.pop("step_index")
         self.sampler.update_guidance(global_t=step_index)
-        sampler_kwargs = {k: kwargs[k] for k in ("noise_init", "noise_steps", "generator") if k in kwargs}
+        sampler_kwargs = {k: kwargs[k] for k in ("noise_init", "noise_steps", "generator", "use_graph")
+                          if k in kwargs}
         out = self.forward(obs_dict, num_samp=num_action_samples, class_free_guide_w=class_free_guide_w,
                            guide_as_filter_only=guide_as_filter_only, guide_clean=guide_clean,
                            **sampler_kwargs)

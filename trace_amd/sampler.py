@@ -63,6 +63,7 @@ class TraceSampler:
         p.max_steer, p.max_yawvel = cfg.max_steer, cfg.max_yawvel
         self._dyn = p
         self._bufs = {}
+        self._graphs = {}
         add = torch.tensor(cfg.norm_add, dtype=torch.float32, device=self.device)
         div = torch.tensor(cfg.norm_div, dtype=torch.float32, device=self.device)
         self._add, self._div = add, div
@@ -147,21 +148,23 @@ class TraceSampler:
     def forward(self, data_batch, num_samp=1, return_diffusion=False, return_guidance_losses=False,
                 class_free_guide_w=0.0, apply_guidance=True, guide_clean=False,
                 noise_init=None, noise_steps=None, generator=None, n_steps=None, x_init=None,
-                steps=None):
+                steps=None, use_graph=False):
         """DiffuserModel.forward (trace.py:450-500).  Extra keyword arguments:
         noise_init (B,N,T,6) / noise_steps (S,B*N,T,2): injected noise in the reference's draw
         order (trace.py:721,655), else drawn on the device; n_steps: run only the first n reverse
         steps (profiling); x_init (B*N,T,6) + steps [t,...]: start from a given scaled state and
-        run the listed diffusion steps (teacher-forced parity tests)."""
+        run the listed diffusion steps (teacher-forced parity tests); use_graph: capture the
+        step loop into a hipGraph on first use and replay it afterwards (launch-bound batches)."""
         with torch.cuda.device(self.device):
             return self._forward(data_batch, num_samp, return_diffusion, return_guidance_losses,
                                  float(class_free_guide_w), apply_guidance, guide_clean, noise_init,
-                                 noise_steps, generator, n_steps, x_init, steps)
+                                 noise_steps, generator, n_steps, x_init, steps, use_graph)
 
     __call__ = forward
 
     def _forward(self, data_batch, N, return_diffusion, return_guidance_losses, w, apply_guidance,
-                 guide_clean, noise_init, noise_steps, generator, n_steps, x_init=None, steps=None):
+                 guide_clean, noise_init, noise_steps, generator, n_steps, x_init=None, steps=None,
+                 use_graph=False):
         cfg, L, dev = self.cfg, self.lib, self.device
         st = self._stream()
         use_cfg = w != 0.0
@@ -171,14 +174,20 @@ class TraceSampler:
         M = B * N
         R = 2 * M if use_cfg else M
         dyn = C.byref(self._dyn)
-        curr = aux["curr_states"]
-        rfa = aux["raster_from_agent"]
         Cg = cfg.map_grid_feature_dim
         Hg, Wg = aux["map_grid_feat"].shape[-2:]
-        grid = self._f32(aux["map_grid_feat"]).permute(0, 2, 3, 1).contiguous()
+        # Everything the step loop reads lives in buffers owned by the sampler (one per name and
+        # shape), so a captured hipGraph of the loop can be replayed on the next call's inputs.
+        curr = self._buf("curr", (B, 4))
+        curr.copy_(aux["curr_states"])
+        rfa = self._buf("rfa", (B, 3, 3))
+        rfa.copy_(aux["raster_from_agent"])
+        grid = self._buf("grid", (B, Hg, Wg, Cg))
+        grid.copy_(self._f32(aux["map_grid_feat"]).permute(0, 2, 3, 1))
         grid_nc = None
         if use_cfg:
-            grid_nc = self._f32(aux["map_grid_feat_non_cond"]).permute(0, 2, 3, 1).contiguous()
+            grid_nc = self._buf("grid_nc", (B, Hg, Wg, Cg))
+            grid_nc.copy_(self._f32(aux["map_grid_feat_non_cond"]).permute(0, 2, 3, 1))
         # per-block additive cond vectors (temporal.py:22-26,44)
         cond_rows = torch.cat([aux["cond_feat"], aux["non_cond_feat"]], 0) if use_cfg else aux["cond_feat"]
         cond_rows = cond_rows.contiguous()
@@ -207,97 +216,137 @@ class TraceSampler:
         img_w, img_h = float(cfg.image_shape[2]), float(cfg.image_shape[1])
 
         # x_T: only the action channels of the initial noise are used (trace.py:721,731)
-        x, x_next = xa, xb
         if x_init is not None:
-            x.copy_(self._f32(x_init).reshape(M, T, 6))
+            xa.copy_(self._f32(x_init).reshape(M, T, 6))
         else:
             if noise_init is None:
                 noise_init = torch.randn(B, N, T, 6, device=dev, generator=generator)
             a0 = self._f32(noise_init).reshape(M, T, 6)[..., 4:6].contiguous()
-            _cabi.check(L.trace_dyn_rollout(ptr(a0), ptr(curr), ptr(x), M, N, T, 1, 1, dyn, st),
+            _cabi.check(L.trace_dyn_rollout(ptr(a0), ptr(curr), ptr(xa), M, N, T, 1, 1, dyn, st),
                         "trace_dyn_rollout")
         if steps is None:
             steps = list(reversed(range(cfg.n_diffusion_steps)))
             if n_steps is not None:
                 steps = steps[:n_steps]
         steps = [int(t) for t in steps]
+        S = len(steps)
         diffusion = None
         if return_diffusion:
-            diffusion = torch.empty(len(steps) + 1, M, T, 6, device=dev)
-            diffusion[0].copy_(x)
+            diffusion = self._buf("diffusion", (S + 1, M, T, 6))
+            diffusion[0].copy_(xa)
+        # all step noise up front (the reference draws one randn_like per step, trace.py:655; an
+        # injected tape keeps its order): the loop itself is then free of RNG state
+        noise = self._buf("noise", (S, M, T, 2))
         if noise_steps is not None:
-            noise_steps = self._f32(noise_steps)
-        layer_losses = None
+            noise.copy_(self._f32(noise_steps)[:S].reshape(S, M, T, 2))
+        else:
+            noise.normal_(generator=generator)
 
-        for k, t in enumerate(steps):
-            sc = self._coefs(t)
-            csc = C.byref(sc)
-            # denoiser input: trajectory + bilinear map features, cond and uncond rows stacked
-            _cabi.check(L.trace_map_query(ptr(x), ptr(grid), ptr(rfa), ptr(x_in), M, N, T, Cg, Hg, Wg,
-                                          C_PAD, img_w, img_h, dyn, st), "trace_map_query")
-            if use_cfg:
-                _cabi.check(L.trace_map_query(ptr(x), ptr(grid_nc), ptr(rfa), x_in[M:].data_ptr(), M, N,
-                                              T, Cg, Hg, Wg, C_PAD, img_w, img_h, dyn, st),
-                            "trace_map_query")
-            _cabi.check(L.trace_unet_forward(self._unet, ptr(x_in), ptr(table), N, t, R, ptr(pred),
-                                             ptr(ws), ws_bytes, save, st), "trace_unet_forward")
-            _cabi.check(L.trace_cfg_combine(ptr(pred), pred[M:].data_ptr() if use_cfg else None, ptr(x),
-                                            ptr(x0), M, T, w, csc, st), "trace_cfg_combine")
-            grad = None
-            if guided:
-                if guide_clean:
-                    xg = x0
-                else:
-                    _cabi.check(L.trace_posterior_mean(ptr(x0), ptr(x), ptr(mean), M, T, csc, st),
-                                "trace_posterior_mean")
-                    xg = mean
-                _cabi.check(L.trace_dyn_rollout(ptr(xg), ptr(curr), ptr(traj), M, N, T, 1, 0, dyn, st),
-                            "trace_dyn_rollout")
-                gtraj.zero_()
-                plan.evaluate(traj, gtraj, st)
-                _cabi.check(L.trace_dyn_adjoint(ptr(xg), ptr(curr), ptr(gtraj), ptr(g_act), M, N, T, dyn,
-                                                st), "trace_dyn_adjoint")
-                if guide_clean:
-                    _cabi.check(L.trace_cfg_combine_adjoint(
-                        ptr(g_act), ptr(gpred), gpred[M:].data_ptr() if use_cfg else None, M, T, w, csc,
-                        st), "trace_cfg_combine_adjoint")
-                    _cabi.check(L.trace_unet_backward_input(self._unet, ptr(gpred), R, ptr(gx), ptr(ws),
-                                                            ws_bytes, st), "trace_unet_backward_input")
-                    grad = gx[:M] + gx[M:] if use_cfg else gx
-                else:
-                    grad = g_act
-            nz = noise_steps[k] if noise_steps is not None else \
-                torch.randn(M, T, 2, device=dev, generator=generator)
-            clean_path = 1 if (plan is not None and guide_clean) else 0
-            _cabi.check(L.trace_posterior_step(ptr(x0), ptr(grad) if grad is not None else None, ptr(x),
-                                               ptr(nz.contiguous()), ptr(curr), ptr(x_next), ptr(a_out), M,
-                                               N, T, clean_path, csc, dyn, st), "trace_posterior_step")
-            if plan is not None and t == steps[-1]:
-                # guidance losses of the final sample, for filtering (trace.py:697-700)
-                _cabi.check(L.trace_dyn_rollout(ptr(a_out), ptr(curr), ptr(traj), M, N, T, 1, 0, dyn, st),
-                            "trace_dyn_rollout")
-                layer_losses = plan.evaluate(traj, None, st)
-            x, x_next = x_next, x
-            if return_diffusion:
-                diffusion[k + 1].copy_(x)
+        def run_loop(plan_):
+            st_ = self._stream()                 # the capturing stream when under graph capture
+            x, x_next = xa, xb
+            losses = None
+            for k, t in enumerate(steps):
+                sc = self._coefs(t)
+                csc = C.byref(sc)
+                # denoiser input: trajectory + bilinear map features, cond and uncond rows stacked
+                _cabi.check(L.trace_map_query(ptr(x), ptr(grid), ptr(rfa), ptr(x_in), M, N, T, Cg, Hg, Wg,
+                                              C_PAD, img_w, img_h, dyn, st_), "trace_map_query")
+                if use_cfg:
+                    _cabi.check(L.trace_map_query(ptr(x), ptr(grid_nc), ptr(rfa), x_in[M:].data_ptr(), M,
+                                                  N, T, Cg, Hg, Wg, C_PAD, img_w, img_h, dyn, st_),
+                                "trace_map_query")
+                _cabi.check(L.trace_unet_forward(self._unet, ptr(x_in), ptr(table), N, t, R, ptr(pred),
+                                                 ptr(ws), ws_bytes, save, st_), "trace_unet_forward")
+                _cabi.check(L.trace_cfg_combine(ptr(pred), pred[M:].data_ptr() if use_cfg else None,
+                                                ptr(x), ptr(x0), M, T, w, csc, st_), "trace_cfg_combine")
+                grad = None
+                if guided:
+                    if guide_clean:
+                        xg = x0
+                    else:
+                        _cabi.check(L.trace_posterior_mean(ptr(x0), ptr(x), ptr(mean), M, T, csc, st_),
+                                    "trace_posterior_mean")
+                        xg = mean
+                    _cabi.check(L.trace_dyn_rollout(ptr(xg), ptr(curr), ptr(traj), M, N, T, 1, 0, dyn, st_),
+                                "trace_dyn_rollout")
+                    gtraj.zero_()
+                    plan_.evaluate(traj, gtraj, st_)
+                    _cabi.check(L.trace_dyn_adjoint(ptr(xg), ptr(curr), ptr(gtraj), ptr(g_act), M, N, T,
+                                                    dyn, st_), "trace_dyn_adjoint")
+                    if guide_clean:
+                        _cabi.check(L.trace_cfg_combine_adjoint(
+                            ptr(g_act), ptr(gpred), gpred[M:].data_ptr() if use_cfg else None, M, T, w,
+                            csc, st_), "trace_cfg_combine_adjoint")
+                        _cabi.check(L.trace_unet_backward_input(self._unet, ptr(gpred), R, ptr(gx), ptr(ws),
+                                                                ws_bytes, st_), "trace_unet_backward_input")
+                        grad = gx[:M] + gx[M:] if use_cfg else gx
+                    else:
+                        grad = g_act
+                clean_path = 1 if (plan_ is not None and guide_clean) else 0
+                _cabi.check(L.trace_posterior_step(ptr(x0), ptr(grad) if grad is not None else None,
+                                                   ptr(x), ptr(noise[k]), ptr(curr), ptr(x_next),
+                                                   ptr(a_out), M, N, T, clean_path, csc, dyn, st_),
+                            "trace_posterior_step")
+                if plan_ is not None and k == S - 1:
+                    # guidance losses of the final sample, for filtering (trace.py:697-700)
+                    _cabi.check(L.trace_dyn_rollout(ptr(a_out), ptr(curr), ptr(traj), M, N, T, 1, 0, dyn,
+                                                    st_), "trace_dyn_rollout")
+                    losses = plan_.evaluate(traj, None, st_)
+                x, x_next = x_next, x
+                if diffusion is not None:
+                    diffusion[k + 1].copy_(x)
+            return x, losses
+
+        if use_graph:
+            x, layer_losses, plan = self._run_graphed(run_loop, plan, (
+                B, N, use_cfg, w, guided, guide_clean, tuple(steps), return_diffusion,
+                None if plan is None else plan.signature()))
+        else:
+            x, layer_losses = run_loop(plan)
 
         pred_traj = x.reshape(B, N, T, 6).clone()
         tr = self.descale_traj(pred_traj)
         out = {
             "trajectories": tr[..., [0, 1, 3]],
             "predictions": {"positions": tr[..., :2], "yaws": tr[..., 3:4]},
-            "curr_states": curr,
+            "curr_states": curr.clone(),
             "pred_traj_scaled": pred_traj,
         }
         if return_diffusion:
-            d = diffusion.reshape(len(steps) + 1, B, N, T, 6).permute(1, 2, 3, 0, 4)
+            d = diffusion.reshape(S + 1, B, N, T, 6).permute(1, 2, 3, 0, 4)
             out["predictions"]["diffusion_steps"] = self.descale_traj(d)
         if plan is not None:
+            if use_graph:
+                layer_losses = [l.clone() for l in layer_losses]
             out["guidance_plan"] = plan
             out["guidance_layer_losses"] = layer_losses
             if return_guidance_losses:
                 out["predictions"]["guide_losses"] = plan.guide_losses(layer_losses)
         return out
+
+    def _run_graphed(self, run_loop, plan, key):
+        """hipGraph replay of the whole step loop (≈45-95 launches per step x 100 steps become one
+        graph launch): small batches are launch-bound (cfg1: 1.8 ms of host time per 0.4 ms of GPU
+        work per step).  The first call with a given (shape, schedule, guidance structure) key runs
+        eagerly and captures; later calls copy their per-call tables into the captured plan and
+        replay."""
+        entry = self._graphs.get(key)
+        if entry is None:
+            x, losses = run_loop(plan)                       # eager: also sets kernel attributes
+            torch.cuda.synchronize(self.device)
+            result = (x.clone(), None if losses is None else [l.clone() for l in losses])
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                gx_, glosses = run_loop(plan)
+            self._graphs[key] = (g, gx_, glosses, plan)
+            # the capture did not execute anything; hand back the eager result
+            return result[0], result[1], plan
+        g, gx_, glosses, gplan = entry
+        if plan is not None:
+            gplan.load_tables_from(plan)
+        g.replay()
+        return gx_, glosses, gplan
 
     # ---- single pieces, exposed for tests / teacher-forced parity -------------------------- #
     @torch.no_grad()
