@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     for (int j = 0; j < NF4; ++j) {
       const unsigned off = spk[j] == 0xffffffffu
                                ? 0xffffffffu     // out of range -> zeros
-                               : (unsigned)(((int)(spk[j] >> 20) * tstride + (int)(spk[j] & 0xfffffu) + cbase) * 4);
+                               : ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u;
       auto v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0)
                       : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
       stg[j] = __builtin_bit_cast(f32x4, v);
@@ -357,7 +357,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     const int rem = f - tr * TILE;
     rem_out = rem;
     const int tg = traj0 + tr;
-    return tg < a.rows ? (unsigned)((tg * tstride + (coff + co0) * L_OUT + rem) * 4) : 0xffffffffu;
+    // unsigned 32-bit byte offset: the launcher guarantees rows * tstride * 4 < 4 GiB
+    return tg < a.rows ? ((unsigned)tg * (unsigned)tstride + (unsigned)((coff + co0) * L_OUT + rem)) * 4u
+                       : 0xffffffffu;
   };
   f32x4 rv[NQ];
   if (a.res) {
