@@ -100,12 +100,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    # TRACE_BENCH_BACKEND=gloo rehearses the multi-process path on a box with fewer GPUs than ranks
+    # (ranks then share devices; RCCL itself refuses two ranks on one GPU)
+    backend = os.environ.get("TRACE_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
     from trace_amd import _cabi
