@@ -71,7 +71,8 @@ __global__ __launch_bounds__(64) void gn_mish_bwd_kernel(const float* __restrict
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ dy, int C, int cg,
-                                                          int rows) {
+                                                          int rows, const float* __restrict__ head_g,
+                                                          const float* __restrict__ head_w) {
   const int ngroups = C / cg;
   const int row = blockIdx.x / ngroups;
   const int g = blockIdx.x - row * ngroups;
@@ -96,7 +97,17 @@ __global__ __launch_bounds__(64) void gn_mish_bwd_kernel(const float* __restrict
       float x = (yb[e] - mean) * rstd;
       float ga = gamma[g * cg + c];
       float z = x * ga + beta[g * cg + c];
-      float gz = db[e] * mish_grad_f(z) * ga;
+      // the final block's upstream gradient is the 1x1 head's dgrad, W^T g (head_g (rows, L, 2)):
+      // formed here instead of by a kernel of its own
+      float up;
+      if (head_g) {
+        const int t = e - c * L;
+        const float* gp = head_g + ((size_t)row * L + t) * 2;
+        up = head_w[g * cg + c] * gp[0] + head_w[C + g * cg + c] * gp[1];
+      } else {
+        up = db[e];
+      }
+      float gz = up * mish_grad_f(z) * ga;
       gg[k] = gz;
       xh[k] = x;
       s1 += gz;
@@ -114,64 +125,74 @@ __global__ __launch_bounds__(64) void gn_mish_bwd_kernel(const float* __restrict
 }
 
 // final 1x1 conv (C -> 2) + transpose:  pred[row][t][o] = b[o] + sum_c W[o][c] f[row][c][t]
-__global__ void head_fwd_kernel(const float* __restrict__ f, const float* __restrict__ w,
-                                const float* __restrict__ b, float* __restrict__ pred, int C, int L,
-                                int rows) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * L) return;
-  int row = idx / L, t = idx - row * L;
-  const float* fb = f + (size_t)row * C * L + t;
-  float a0 = b[0], a1 = b[1];
+// One thread = 4 consecutive positions (16-byte loads / stores); requires L % 4 == 0.
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ f,
+                                                       const float* __restrict__ w,
+                                                       const float* __restrict__ b,
+                                                       float* __restrict__ pred, int C, int L, int rows) {
+  const int nq = L >> 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * nq) return;
+  const int row = idx / nq, t0 = (idx - row * nq) * 4;
+  const float* fb = f + (size_t)row * C * L + t0;
+  float a0[4] = {b[0], b[0], b[0], b[0]}, a1[4] = {b[1], b[1], b[1], b[1]};
   for (int c = 0; c < C; ++c) {
-    float v = fb[(size_t)c * L];
-    a0 = fmaf(w[c], v, a0);
-    a1 = fmaf(w[C + c], v, a1);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(fb + (size_t)c * L);
+    const float w0 = w[c], w1 = w[C + c];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a0[i] = fmaf(w0, v[i], a0[i]);
+      a1[i] = fmaf(w1, v[i], a1[i]);
+    }
   }
-  pred[(size_t)idx * 2] = a0;
-  pred[(size_t)idx * 2 + 1] = a1;
-}
-
-// df[row][c][t] = sum_o W[o][c] g[row][t][o]
-__global__ void head_bwd_kernel(const float* __restrict__ g, const float* __restrict__ w,
-                                float* __restrict__ df, int C, int L, int rows) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * C * L) return;
-  int row = idx / (C * L);
-  int rem = idx - row * C * L;
-  int c = rem / L, t = rem - c * L;
-  const float* gb = g + ((size_t)row * L + t) * 2;
-  df[idx] = w[c] * gb[0] + w[C + c] * gb[1];
+  f32x4* out = reinterpret_cast<f32x4*>(pred + ((size_t)row * L + t0) * 2);
+  out[0] = f32x4{a0[0], a1[0], a0[1], a1[1]};
+  out[1] = f32x4{a0[2], a1[2], a0[3], a1[3]};
 }
 
 // Input gradient of the first residual block restricted to input channels [c_lo, c_lo+2):
 //   gx[row][t][j] = sum_{co,tap} dy1[row][co][t+2-tap] W1[co][c_lo+j][tap] + sum_co dout[row][co][t] Wr[co][c_lo+j]
 // wsel: [2][cout][5] conv taps, rsel: [2][cout] residual 1x1 (pre-gathered on the host).
-__global__ void first_dgrad_kernel(const float* __restrict__ dy1, const float* __restrict__ dout,
-                                   const float* __restrict__ wsel, const float* __restrict__ rsel,
-                                   float* __restrict__ gx, int C, int L, int rows) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * L) return;
-  int row = idx / L, t = idx - row * L;
-  const float* yb = dy1 + (size_t)row * C * L;
-  const float* ob = dout + (size_t)row * C * L;
-  float a0 = 0.f, a1 = 0.f;
+// One thread = 4 consecutive positions of one row: three aligned 16-byte loads of dy1 (the 12-wide
+// window around them; out-of-range quarters are zeros = the conv's zero padding) and one of dout
+// per channel feed 48 FMAs (the per-position form issued 6 scalar loads per 12 FMAs and ran at a
+// quarter of the HBM rate).  Requires L % 4 == 0.
+__global__ __launch_bounds__(256) void first_dgrad_kernel(const float* __restrict__ dy1,
+                                                          const float* __restrict__ dout,
+                                                          const float* __restrict__ wsel,
+                                                          const float* __restrict__ rsel,
+                                                          float* __restrict__ gx, int C, int L, int rows) {
+  const int nq = L >> 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * nq) return;
+  const int row = idx / nq, q = idx - row * nq, t0 = q * 4;
+  const float* yb = dy1 + (size_t)row * C * L + t0;
+  const float* ob = dout + (size_t)row * C * L + t0;
+  float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   for (int co = 0; co < C; ++co) {
     const float* yr = yb + (size_t)co * L;
+    const f32x4 lo = q > 0 ? *reinterpret_cast<const f32x4*>(yr - 4) : zero;
+    const f32x4 mi = *reinterpret_cast<const f32x4*>(yr);
+    const f32x4 hi = q + 1 < nq ? *reinterpret_cast<const f32x4*>(yr + 4) : zero;
+    const f32x4 o = *reinterpret_cast<const f32x4*>(ob + (size_t)co * L);
+    const float v[12] = {lo[0], lo[1], lo[2], lo[3], mi[0], mi[1], mi[2], mi[3], hi[0], hi[1], hi[2], hi[3]};
+    const float r0 = rsel[co], r1 = rsel[C + co];
 #pragma unroll
-    for (int tap = 0; tap < 5; ++tap) {
-      int p = t + 2 - tap;
-      if (p >= 0 && p < L) {
-        float v = yr[p];
-        a0 = fmaf(v, wsel[co * 5 + tap], a0);
-        a1 = fmaf(v, wsel[(C + co) * 5 + tap], a1);
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int tap = 0; tap < 5; ++tap) {
+        const float x = v[i + 6 - tap];            // position t0 + i + 2 - tap
+        a0[i] = fmaf(x, wsel[co * 5 + tap], a0[i]);
+        a1[i] = fmaf(x, wsel[(C + co) * 5 + tap], a1[i]);
       }
+      a0[i] = fmaf(o[i], r0, a0[i]);
+      a1[i] = fmaf(o[i], r1, a1[i]);
     }
-    float o = ob[(size_t)co * L + t];
-    a0 = fmaf(o, rsel[co], a0);
-    a1 = fmaf(o, rsel[C + co], a1);
   }
-  gx[(size_t)idx * 2] = a0;
-  gx[(size_t)idx * 2 + 1] = a1;
+  f32x4* out = reinterpret_cast<f32x4*>(gx + ((size_t)row * L + t0) * 2);
+  out[0] = f32x4{a0[0], a1[0], a0[1], a1[1]};
+  out[1] = f32x4{a0[2], a1[2], a0[3], a1[3]};
 }
 
 // table[r][j] = bias[j] + sum_k W[j][k] mish(cond[r][k])
@@ -759,12 +780,13 @@ void set_res2(ConvArgs& a, const View& r) {
 }
 
 int run_gn_bwd(const View& da, const float* y, const float* stats, const float* gamma,
-               const float* beta, float* dy, int C, int L, int rows, hipStream_t st) {
+               const float* beta, float* dy, int C, int L, int rows, hipStream_t st,
+               const float* head_g = nullptr, const float* head_w = nullptr) {
   int cg = C / 8;
   dim3 grid(rows * 8);
 #define GNB(LL)                                                                              \
   hipLaunchKernelGGL(gn_mish_bwd_kernel<LL>, grid, dim3(64), 0, st, da.p, da.tstride(), da.coff, \
-                     y, stats, gamma, beta, dy, C, cg, rows)
+                     y, stats, gamma, beta, dy, C, cg, rows, head_g, head_w)
   if (L == 52) GNB(52);
   else if (L == 26) GNB(26);
   else if (L == 13) GNB(13);
@@ -883,7 +905,8 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in, const float*
     RUN(run_conv(K_CONV5, H, a, st));
   }
   {
-    int n = rows * H;
+    TRACE_REQUIRE(H % 4 == 0, "head: horizon %d not a multiple of 4", H);
+    int n = rows * (H / 4);
     hipLaunchKernelGGL(head_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, f.p, u->head_w,
                        u->head_b, pred, d0, H, rows);
     RUN(launch_status("head_fwd_kernel"));
@@ -951,12 +974,8 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
 
   // head + final block
   {
-    int n = rows * d0 * H;
-    hipLaunchKernelGGL(head_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, grad_pred,
-                       u->head_w, G0, d0, H, rows);
-    RUN(launch_status("head_bwd_kernel"));
     View g0{G0, d0, 0, H}, t1{T1, d0, 0, H}, g1{G1, d0, 0, H};
-    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, T1, d0, H, rows, st));
+    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, T1, d0, H, rows, st, grad_pred, u->head_w));
     RUN(run_conv(K_CONV5, H, conv_args(t1, u->final_b, nullptr, g1, rows), st));
   }
   // up1 (ConvT d0: L/2 -> L): its dgrad output is dout of block 11
@@ -1007,7 +1026,8 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
     ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
     set_gnb(a, buf(u->b_y1[0]), buf(u->b_s1[0]), b.g1, b.be1, b.cout, t2, nullptr);
     RUN(run_conv(K_CONV5, b.L, a, st));
-    int n = rows * H;
+    TRACE_REQUIRE(H % 4 == 0, "first_dgrad: horizon %d not a multiple of 4", H);
+    int n = rows * (H / 4);
     hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, T2, G0,
                        u->first_wsel, u->first_rsel, grad_x, d0, H, rows);
     RUN(launch_status("first_dgrad_kernel"));
