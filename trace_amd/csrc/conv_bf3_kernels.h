@@ -1,0 +1,310 @@
+// Implicit-GEMM Conv1d on the bf16 matrix pipe with fp32 results: every fp32 operand is split
+// exactly into three bf16 terms, a = h + m + l (round-to-nearest at each step, so the three terms
+// carry all 24 significand bits), and a product a*b is accumulated as the six terms
+//     l*h' + h*l' + m*m' + m*h' + h*m' + h*h'
+// on v_mfma_f32_16x16x32_bf16 (fp32 accumulate; the dropped m*l', l*m', l*l' are below 2^-25 of
+// the product).  Measured against an fp64 sum at K = 1280 (scripts/probe/bf16x3.hip): rms relative
+// error 5.3e-7, the native fp32 MFMA 5.8e-7; rate 405 vs 154 fp32-equivalent TFLOP/s.
+//
+// Same tile as conv_gemm_kernel (conv_kernels.h): 208 rows x 64 output channels per workgroup, wave w
+// owns channels 16w .. 16w+15 and all 13 row tiles, identical accumulator layout, so the fused
+// epilogues (GroupNorm + Mish forward / backward, residuals) are shared.
+//
+// A operand: activations stay fp32 in HBM.  A chunk of 32 channels is fetched global -> VGPR
+//            (8 channels x 1 position per thread and pass, dword buffer loads coalesced along the
+//            position axis), split in registers, and written as three bf16 planes
+//            [plane][position][32 channels + pad] with one ds_write_b128 per plane; a lane's MFMA
+//            fragment (8 consecutive channels of one position) is one ds_read_b128 per plane.
+//            Position stride 80 B = 5 sixteen-byte slots (odd -> 16 consecutive positions hit 16
+//            different slots).
+// B operand: weights split and packed on the host in fragment order [col tile][slice][plane][lane],
+//            streamed L2 -> VGPR two slices (one slice = one tap x 32 channels) ahead.
+// K loop   : fully unrolled over the taps of a chunk; the A fragments of row tile n+2 are requested
+//            while tile n multiplies (3 register stages), 6 MFMAs per (row tile, slice).
+#pragma once
+#include <cstdint>
+#include <type_traits>
+
+#include "conv_kernels.h"
+
+namespace trace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// 8 fp32 values -> three bf16 planes (exact three-way split)
+__device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4v& h, u32x4v& m, u32x4v& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = v[2 * i], a1 = v[2 * i + 1];
+    const unsigned ph = cvt_pk_bf16(a0, a1);
+    const float r0 = a0 - __builtin_bit_cast(float, ph << 16);
+    const float r1 = a1 - __builtin_bit_cast(float, ph & 0xffff0000u);
+    const unsigned pm = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, pm << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, pm & 0xffff0000u);
+    h[i] = ph;
+    m[i] = pm;
+    l[i] = cvt_pk_bf16(s0, s1);
+  }
+}
+
+template <int L_OUT, int UP, int TAPS, int PADL, int TB>
+struct Bf3Geom {
+  static constexpr int CH = 32;                            // channels per chunk = one MFMA k-slice per tap
+  static constexpr int R = TB * L_OUT;
+  static constexpr int NRT = R / 16;
+  static constexpr int LP = (L_OUT - 1) + TAPS;            // staged positions per trajectory (stride 1)
+  static constexpr int S = TB * LP;
+  static constexpr int L_IN = L_OUT / UP;
+  static constexpr int ROWB = 2 * CH + 16;                 // bytes per position per plane
+  static constexpr int PLANE = S * ROWB;                   // bytes per plane
+  static constexpr int NPOS = TB * L_IN;                   // data positions per chunk
+  static constexpr int NU = NPOS * (CH / 8);               // staging units (position, channel octet)
+  static constexpr int NUT = (NU + 255) / 256;
+  static constexpr size_t EPI_BYTES = ((size_t)R * 64 + (size_t)TB * 64 * 4) * sizeof(float);
+  static constexpr size_t LDS_BYTES = (size_t)3 * PLANE > EPI_BYTES ? (size_t)3 * PLANE : EPI_BYTES;
+  static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0, "bad tile");
+  static_assert((ROWB / 16) % 2 == 1, "position stride must be an odd number of 16-byte slots");
+  static_assert(2 * PLANE + (TAPS + 1) * ROWB < 65536, "LDS immediates must fit 16 bits");
+};
+
+template <int L_OUT, int UP, int TAPS, int PADL, int TB>
+__global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB>;
+  constexpr int NRT = G::NRT, LP = G::LP, L_IN = G::L_IN, ROWB = G::ROWB, PLANE = G::PLANE;
+  constexpr int NUT = G::NUT, NU = G::NU, NPOS = G::NPOS, CH = G::CH;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  char* const ldsb = reinterpret_cast<char*>(lds);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  // workgroup id -> (row block, column tile): see conv_gemm_kernel
+  const int ncol = a.cout >> 6;
+  const int bid = blockIdx.x;
+  const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
+  const int ct = (bid >> 3) % ncol;
+  if (rb * TB >= a.rows) return;
+  const int traj0 = rb * TB;
+  const int co0 = ct * 64;
+  TRACE_STAMP(0);
+
+  // ---- staging ------------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in2 ? a.in2 : a.in), 0,
+      a.in2 ? (unsigned)((size_t)a.rows * a.in2_tstride * sizeof(float)) : 0u, 0x00020000);
+  const int nch1 = a.cin / CH;
+  const int nch = nch1 + a.cin2 / CH;
+  // unit q = tid + 256 j: octet o = q / NPOS, position pp = q % NPOS (lanes run along positions)
+  unsigned spk[NUT];            // (trajectory in tile) << 20 | float offset inside the chunk
+  unsigned wofs[NUT];           // LDS byte offset of the unit inside a plane
+#pragma unroll
+  for (int j = 0; j < NUT; ++j) {
+    const int q = tid + 256 * j;
+    const int o = q / NPOS;
+    const int pp = q - o * NPOS;
+    const int tr = pp / L_IN;
+    const int i = pp - tr * L_IN;
+    spk[j] = ((unsigned)tr << 20) | (unsigned)(o * 8 * L_IN + i);
+    wofs[j] = (unsigned)((tr * LP + i * UP + PADL) * ROWB + o * 16);
+  }
+  float stg[NUT][8];
+  auto stage_load = [&](int ch) {
+    const bool second = ch >= nch1;
+    const int tstride = second ? a.in2_tstride : a.in_tstride;
+    const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
+                      traj0 * tstride;
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+      // units past NU (last pass) read a valid address and are never written to LDS; trajectories
+      // past `rows` fall outside the descriptor's range and read as zeros
+      const bool live = (NU % 256 == 0) || (tid + 256 * j < NU);
+      const unsigned off = live ? ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u : 0u;
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        stg[j][jj] = second ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, jj * L_IN * 4, 0))
+                            : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, jj * L_IN * 4, 0));
+      }
+    }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int j = 0; j < NUT; ++j) {
+      if ((NU % 256 == 0) || (tid + 256 * j < NU)) {
+        u32x4v h, m, l;
+        split8_bf16(stg[j], h, m, l);
+        char* p = ldsb + wofs[j];
+        *reinterpret_cast<u32x4v*>(p) = h;
+        *reinterpret_cast<u32x4v*>(p + PLANE) = m;
+        *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = l;
+      }
+    }
+  };
+
+  stage_load(0);
+  // halo / zero-stuffing positions are written once; data positions are rewritten by every chunk
+  if constexpr (UP == 1 && TAPS == 1) {
+  } else if constexpr (UP == 1) {
+    constexpr int HALO = TAPS - 1;                       // PADL of them in front of the data
+    constexpr int Q = ROWB / 16;
+    for (int i = tid; i < 3 * TB * HALO * Q; i += 256) {
+      const int pl = i / (TB * HALO * Q);
+      const int r0 = i - pl * (TB * HALO * Q);
+      const int tr = r0 / (HALO * Q);
+      const int r = r0 - tr * (HALO * Q);
+      const int h = r / Q;
+      const int pos = tr * LP + (h < PADL ? h : L_IN + h);
+      *reinterpret_cast<u32x4v*>(ldsb + pl * PLANE + pos * ROWB + (r - h * Q) * 16) = u32x4v{0u, 0u, 0u, 0u};
+    }
+  } else {
+#pragma unroll 2
+    for (int i = tid; i < 3 * PLANE / 16; i += 256)
+      reinterpret_cast<u32x4v*>(ldsb)[i] = u32x4v{0u, 0u, 0u, 0u};
+  }
+
+  // lane (row = lane & 15, kq = lane >> 4) reads channels 8 kq .. 8 kq + 7 of its output row's input
+  // position: one ds_read_b128 per plane
+  int rowoff[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    const int r = rt * 16 + (lane & 15);
+    const int tr = r / L_OUT;
+    const int l = r - tr * L_OUT;
+    rowoff[rt] = (tr * LP + l) * ROWB + (lane >> 4) * 16;
+  }
+  f32x4 acc[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wb) + ((size_t)(ct * 4 + wave) * a.nsl) * 192 + lane;
+  bf16x8 bn1[3], bn2[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) bn1[p] = wp[64 * p];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) bn2[p] = a.nsl > 1 ? wp[192 + 64 * p] : bn1[p];
+  int sdone = 0;
+
+  // one chunk's MFMAs over taps [T0, T1)
+  auto chunk_mma = [&](auto t0c, auto t1c) {
+    constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
+    constexpr int NT = (T1 - T0) * NRT;
+    bf16x8 av[3][3];
+    auto load_a = [&](int n, int stage) {
+      const int tap = T0 + n / NRT, rt = n % NRT;
+      const char* p = ldsb + rowoff[rt] + tap * ROWB;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) av[stage][pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
+    };
+    load_a(0, 0);
+    if (NT > 1) load_a(1, 1);
+    bf16x8 b[3];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      if (n % NRT == 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
+        ++sdone;
+        wp += 192;
+        if (sdone + 1 < a.nsl) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) bn2[p] = wp[192 + 64 * p];
+        }
+      }
+      if (n + 2 < NT) load_a(n + 2, (n + 2) % 3);
+      const int s = n % 3, rt = n % NRT;
+      f32x4 c = acc[rt];
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][2], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[2], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][1], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][1], b[0], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[1], c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[0], c, 0, 0, 0);
+      acc[rt] = c;
+    }
+  };
+
+  TRACE_STAMP(14);
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();            // previous chunk fully consumed (and zero fill done)
+    stage_write();
+    if (ch == 0) TRACE_STAMP(15);
+    if (ch + 1 < nch) stage_load(ch + 1);       // in flight during this chunk's MFMAs
+    __syncthreads();
+    if (ch == 0) TRACE_STAMP(1);
+    if (ch < nch1)
+      chunk_mma(std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{});
+    else
+      chunk_mma(std::integral_constant<int, PADL>{}, std::integral_constant<int, PADL + 1>{});
+    if (ch < 4) TRACE_STAMP(2 + ch);
+  }
+
+  conv_epilogue<L_OUT, TB>(a, acc, lds, traj0, co0);
+}
+
+template <int L_OUT, int UP, int TAPS, int PADL, int TB>
+int launch_conv_bf3(const ConvArgs& a_in, hipStream_t st) {
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB>;
+  ConvArgs a = a_in;
+  if (a.rows <= 0) return TRACE_OK;
+  TRACE_REQUIRE(a.wb && a.cout % 64 == 0 && a.cin % 32 == 0 && a.cin2 % 32 == 0 &&
+                    a.nsl == TAPS * a.cin / 32 + a.cin2 / 32,
+                "conv(bf16x3): bad channel geometry cin=%d cin2=%d cout=%d nsl=%d", a.cin, a.cin2, a.cout,
+                a.nsl);
+  TRACE_REQUIRE(a.cin2 == 0 || (a.in2 && UP == 1 && a.in2_tstride % 4 == 0 &&
+                                (size_t)(a.rows + TB) * a.in2_tstride * sizeof(float) < 0xffffffffull),
+                "conv(bf16x3): second K source needs a stride-1 conv and a tensor below 4 GiB");
+  TRACE_REQUIRE(!a.gnb || (!a.gn && !a.pc && !a.ysave && a.gb_y && a.gb_stats && a.gb_gamma && a.gb_beta &&
+                           a.gb_cg > 0 && (a.gb_cg & (a.gb_cg - 1)) == 0 && a.gb_cg <= 64 &&
+                           a.gb_cmax % 64 == 0 && a.gb_cmax <= a.gb_c &&
+                           (reinterpret_cast<uintptr_t>(a.gb_y) & 15) == 0),
+                "conv(bf16x3): bad GroupNorm-backward epilogue arguments");
+  TRACE_REQUIRE(!a.gn || (a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64), "conv: group size %d",
+                a.cg);
+  TRACE_REQUIRE((reinterpret_cast<uintptr_t>(a.in) & 3) == 0 &&
+                    (size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull,
+                "conv(bf16x3): input of %d rows exceeds the 4 GiB buffer-descriptor range; split the rows",
+                a.rows);
+  auto ok128 = [&](const float* p, int tstride, int coff) {
+    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 &&
+                            (coff * L_OUT) % 4 == 0 &&
+                            (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
+  };
+  TRACE_REQUIRE(ok128(a.out, a.out_tstride, a.out_coff) && ok128(a.res, a.res_tstride, a.res_coff) &&
+                    ok128(a.res2, a.res2_tstride, a.res2_coff) && ok128(a.ysave, a.cout * L_OUT, 0) &&
+                    ok128(a.out_raw, a.raw_tstride, a.raw_coff),
+                "conv(bf16x3): output / residual tensors must be 16-byte aligned per trajectory tile and "
+                "below 4 GiB (%d rows)", a.rows);
+  TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
+  constexpr size_t lds_bytes = G::LDS_BYTES;
+  static_assert(lds_bytes <= 80 * 1024, "conv(bf16x3): LDS per workgroup too large for two per CU");
+  static bool attr_set = false;
+  if (!attr_set) {
+    TRACE_CHECK_HIP(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_set = true;
+  }
+  const int nrb = (a.rows + TB - 1) / TB;
+  dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 64));
+#ifdef TRACE_CONV_STAMPS
+  a.dbg = stamp_buffer_for_next_launch();
+#endif
+  const bool prof = prof_active();
+  if (prof) prof_pre(st);
+  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB>), grid, dim3(256), lds_bytes, st, a);
+  if (prof) prof_post(st, 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT);
+  return launch_status("conv_bf3_kernel");
+}
+
+}  // namespace trace

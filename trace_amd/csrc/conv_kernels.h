@@ -80,6 +80,9 @@ struct ConvArgs {
   float* out_raw;      // or null
   int raw_tstride;
   int raw_coff;
+  // split-bf16 weight stream (conv_bf3_kernels.h): [cout/16][nsl][3 planes][64 lanes] x 8 bf16, or null
+  const void* wb;
+  int nsl;             // k-slices of 32 = taps * cin / 32 + cin2 / 32
   unsigned long long* dbg;   // diagnostic builds only (TRACE_CONV_STAMPS): 16 time stamps per workgroup
 };
 
@@ -145,211 +148,24 @@ __device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
   }
 }
 
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
-struct ConvGeom {
-  static constexpr int R = TB * L_OUT;
-  static constexpr int NRT = R / 16;
-  static constexpr int LP = (L_OUT - 1) * IN_STRIDE + TAPS;
-  static constexpr int S = TB * LP;                        // staged positions (with halo)
-  static constexpr int CHS = CH + 4;                       // LDS floats per position: CHS/4 odd
-  static constexpr int L_IN = (L_OUT * IN_STRIDE) / UP;
-  static constexpr int RS = R + 4;
-  static constexpr int F4_PER_TRAJ = CH * L_IN / 4;        // float4 per trajectory per chunk
-  static constexpr int F4_TOTAL = TB * F4_PER_TRAJ;
-  static constexpr int NF4 = (F4_TOTAL + 255) / 256;       // staging registers (float4) per thread
-  static constexpr int KBPC = CH / 16;
-  static constexpr int NKK = TAPS * KBPC;
-  static_assert(R % 16 == 0, "row block must be a whole number of MFMA tiles");
-  static_assert((CH * L_IN) % 4 == 0 && CH % 16 == 0, "chunk must be float4 / k-block aligned");
-  static_assert((CHS / 4) % 2 == 1, "position stride must be an odd number of 16-byte slots");
-  static constexpr int NQ = R * 64 / 4 / 256;              // output float4 per thread
-  static_assert(R * 64 % 1024 == 0 && TB % 4 == 0, "output tile must split evenly over 256 threads");
-  static constexpr size_t EPI_FLOATS = (size_t)R * 64 + (size_t)TB * 64 * 4;   // tile + tables
-  static constexpr size_t LDS_FLOATS = ((size_t)CHS * S > EPI_FLOATS) ? (size_t)CHS * S : EPI_FLOATS;
-};
-
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
-  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
-  constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, R = G::R, CHS = G::CHS;
-  constexpr int NF4 = G::NF4, KBPC = G::KBPC, NKK = G::NKK;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
+// ---- epilogue (shared by the fp32 and the split-bf16 K loops) ------------------------------
+// The 208 x 64 accumulator tile of a workgroup (wave w owns output channels 16w .. 16w+15 and all
+// NRT row tiles, MFMA C layout: column = lane & 15, rows 4 (lane >> 4) + reg) goes through LDS once,
+// laid out exactly like the global tensors ([trajectory][channel][position], TILE floats per
+// trajectory), so that
+//   E1  per-(trajectory, channel) rows are contiguous  -> GroupNorm statistics in registers
+//   E2  the whole tile is one flat stream              -> 128-bit LDS reads and global accesses
+// Residual operands are fetched into registers before anything else: their latency hides
+// under E0/E1 instead of serialising the store loop.
+template <int L_OUT, int TB>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB * L_OUT / 16], float* lds,
+                                              const int traj0, const int co0) {
+  constexpr int R = TB * L_OUT, NRT = R / 16;
+  constexpr int TILE = 64 * L_OUT;
+  constexpr int NQ = R * 64 / 4 / 256;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  // Workgroup id -> (row block, column tile).  Consecutive ids go round-robin over the 8 XCDs
-  // (id % 8), each with its own L2, so the ncol column tiles of one row block -- which all stage
-  // the same activations -- are given ids of the same residue, 8 apart: they run at the same time
-  // behind the same L2 and the input comes from HBM once instead of ncol times.
-  const int ncol = a.cout >> 6;
-  const int bid = blockIdx.x;
-  const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
-  const int ct = (bid >> 3) % ncol;
-  if (rb * TB >= a.rows) return;               // padding ids of the last group of 8 row blocks
-  const int traj0 = rb * TB;
-  const int co0 = ct * 64;
-  TRACE_STAMP(0);
-#ifdef TRACE_CONV_STAMPS
-  if (a.dbg && threadIdx.x == 0) {
-    a.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
-    a.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
-  }
-#endif
-
-  // ---- staging: thread handles float4 #(tid + 256 j) of the chunk -------------------------
-  // Buffer loads with a 32-bit byte offset: the descriptor's range check returns 0 for
-  // trajectories past `rows` (tail workgroup), so there is no per-load predicate.
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
-      0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in2 ? a.in2 : a.in), 0,
-      a.in2 ? (unsigned)((size_t)a.rows * a.in2_tstride * sizeof(float)) : 0u, 0x00020000);
-  const int nch1 = a.cin / CH;
-  const int nch = nch1 + a.cin2 / CH;
-  unsigned spk[NF4];            // (trajectory in tile) << 20 | float offset inside the chunk
-#pragma unroll
-  for (int j = 0; j < NF4; ++j) {
-    const int q = tid + 256 * j;
-    const int tr = q / G::F4_PER_TRAJ;
-    const int rem = q - tr * G::F4_PER_TRAJ;
-    spk[j] = q < G::F4_TOTAL ? ((unsigned)tr << 20) | (unsigned)(rem * 4) : 0xffffffffu;
-  }
-  f32x4 stg[NF4];
-  auto stage_load = [&](int ch) {
-    const bool second = ch >= nch1;
-    const int tstride = second ? a.in2_tstride : a.in_tstride;
-    const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
-                      traj0 * tstride;
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const unsigned off = spk[j] == 0xffffffffu
-                               ? 0xffffffffu     // out of range -> zeros
-                               : ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u;
-      auto v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0)
-                      : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-      stg[j] = __builtin_bit_cast(f32x4, v);
-    }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int q = tid + 256 * j;
-      if (q < G::F4_TOTAL) {
-        const int tr = q / G::F4_PER_TRAJ;
-        const int e0 = (q - tr * G::F4_PER_TRAJ) * 4;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u;
-          const int ci = e / L_IN;
-          const int i = e - ci * L_IN;
-          lds[(tr * LP + i * UP + PADL) * CHS + ci] = stg[j][u];
-        }
-      }
-    }
-  };
-
-  stage_load(0);
-  // halo / zero-stuffing positions are written once; data positions are the same for every chunk
-  if constexpr (UP == 1 && IN_STRIDE == 1 && TAPS == 1) {
-    // 1x1 conv: no halo, every position is overwritten by stage_write
-  } else if constexpr (UP == 1 && IN_STRIDE == 1) {
-    // every data position is overwritten by stage_write: only the TAPS-1 halo positions per
-    // trajectory need zeros
-    constexpr int HALO = LP - L_IN;                     // = TAPS - 1, PADL of them in front
-    constexpr int Q = CHS / 4;
-    for (int i = tid; i < TB * HALO * Q; i += 256) {
-      const int tr = i / (HALO * Q);
-      const int r = i - tr * (HALO * Q);
-      const int h = r / Q;
-      const int pos = tr * LP + (h < PADL ? h : L_IN + h);
-      reinterpret_cast<f32x4*>(lds)[pos * Q + (r - h * Q)] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  } else {
-#pragma unroll 2
-    for (int i = tid; i < CHS * S / 4; i += 256)
-      reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // LDS image is [position][channel]; lane (row = lane&15, kq = lane>>4) reads the 4 channels
-  // 16m + 4kq .. +3 of its output row's input position with one ds_read_b128, and feeds element
-  // u to MFMA pass u (the host packs the weights in the matching k order)
-  int rowoff[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) {
-    int r = rt * 16 + (lane & 15);
-    int tr = r / L_OUT;
-    int l = r - tr * L_OUT;
-    rowoff[rt] = (tr * LP + l * IN_STRIDE) * CHS + (lane >> 4) * 4;
-  }
-  f32x4 acc[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const f32x4* wp = a.wp + ((size_t)(ct * 4 + wave) * a.nkb) * 64 + lane;
-  f32x4 bnext = *wp;
-  f32x4 bnext2 = a.nkb > 1 ? wp[64] : bnext;
-  int kdone = 0;
-
-  TRACE_STAMP(14);
-  for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();            // previous chunk fully consumed (and zero fill done)
-    stage_write();
-    if (ch == 0) TRACE_STAMP(15);
-    if (ch + 1 < nch) stage_load(ch + 1);       // in flight during this chunk's K loop
-    __syncthreads();
-
-    // K loop over the staged chunk.  One ds_read_b128 per (row tile, k-block) supplies the A
-    // values of 4 MFMA passes; the read for the NEXT k-block is issued right after the last pass
-    // that consumes the register, i.e. 13 MFMAs (>400 cycles) ahead of its first use.
-    // Chunks of the second source contribute at the centre tap only.
-    if (ch == 0) TRACE_STAMP(1);
-    const bool second = ch >= nch1;
-    int kk = second ? PADL * KBPC : 0;
-    const int kk_end = second ? (PADL + 1) * KBPC : NKK;
-    int tap = second ? PADL : 0, kb = 0;
-    f32x4 av[NRT];
-    const float* lp = lds + tap * CHS;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(lp + rowoff[rt]);
-    for (; kk < kk_end; ++kk) {
-      const f32x4 b = bnext;
-      bnext = bnext2;
-      ++kdone;
-      wp += 64;
-      if (kdone + 1 < a.nkb) bnext2 = wp[64];
-      int kb2 = kb + 1, tap2 = tap;
-      if (kb2 == KBPC) { kb2 = 0; ++tap2; }
-      const float* lpn = lds + tap2 * CHS + kb2 * 16;
-      const bool more = kk + 1 < kk_end;
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][u], b[u], acc[rt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], b[3], acc[rt], 0, 0, 0);
-        if (more) av[rt] = *reinterpret_cast<const f32x4*>(lpn + rowoff[rt]);
-      }
-      lp = lpn;
-      kb = kb2;
-      tap = tap2;
-    }
-    if (ch < 4) TRACE_STAMP(2 + ch);
-  }
-
-  // ---- epilogue --------------------------------------------------------------------------
-  // The 208 x 64 accumulator tile goes through LDS once, laid out exactly like the global
-  // tensors ([trajectory][channel][position], TILE floats per trajectory), so that
-  //   E1  per-(trajectory, channel) rows are contiguous  -> GroupNorm statistics in registers
-  //   E2  the whole tile is one flat stream              -> 128-bit LDS reads and global accesses
-  // Residual operands are fetched into registers before anything else: their latency hides
-  // under E0/E1 instead of serialising the store loop.
-  constexpr int TILE = 64 * L_OUT;
-  constexpr int NQ = G::NQ;
   const bool has_tab = a.gn || a.pc;
   auto flat_off = [&](int k, int tstride, int coff, int& rem_out) -> unsigned {
     const int f = (tid + 256 * k) * 4;
@@ -655,6 +471,205 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y), ro, oo, 0, 0);
   }
   TRACE_STAMP(11);
+}
+
+template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
+struct ConvGeom {
+  static constexpr int R = TB * L_OUT;
+  static constexpr int NRT = R / 16;
+  static constexpr int LP = (L_OUT - 1) * IN_STRIDE + TAPS;
+  static constexpr int S = TB * LP;                        // staged positions (with halo)
+  static constexpr int CHS = CH + 4;                       // LDS floats per position: CHS/4 odd
+  static constexpr int L_IN = (L_OUT * IN_STRIDE) / UP;
+  static constexpr int RS = R + 4;
+  static constexpr int F4_PER_TRAJ = CH * L_IN / 4;        // float4 per trajectory per chunk
+  static constexpr int F4_TOTAL = TB * F4_PER_TRAJ;
+  static constexpr int NF4 = (F4_TOTAL + 255) / 256;       // staging registers (float4) per thread
+  static constexpr int KBPC = CH / 16;
+  static constexpr int NKK = TAPS * KBPC;
+  static_assert(R % 16 == 0, "row block must be a whole number of MFMA tiles");
+  static_assert((CH * L_IN) % 4 == 0 && CH % 16 == 0, "chunk must be float4 / k-block aligned");
+  static_assert((CHS / 4) % 2 == 1, "position stride must be an odd number of 16-byte slots");
+  static constexpr int NQ = R * 64 / 4 / 256;              // output float4 per thread
+  static_assert(R * 64 % 1024 == 0 && TB % 4 == 0, "output tile must split evenly over 256 threads");
+  static constexpr size_t EPI_FLOATS = (size_t)R * 64 + (size_t)TB * 64 * 4;   // tile + tables
+  static constexpr size_t LDS_FLOATS = ((size_t)CHS * S > EPI_FLOATS) ? (size_t)CHS * S : EPI_FLOATS;
+};
+
+template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
+  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
+  constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, CHS = G::CHS;
+  constexpr int NF4 = G::NF4, KBPC = G::KBPC, NKK = G::NKK;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  // Workgroup id -> (row block, column tile).  Consecutive ids go round-robin over the 8 XCDs
+  // (id % 8), each with its own L2, so the ncol column tiles of one row block -- which all stage
+  // the same activations -- are given ids of the same residue, 8 apart: they run at the same time
+  // behind the same L2 and the input comes from HBM once instead of ncol times.
+  const int ncol = a.cout >> 6;
+  const int bid = blockIdx.x;
+  const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
+  const int ct = (bid >> 3) % ncol;
+  if (rb * TB >= a.rows) return;               // padding ids of the last group of 8 row blocks
+  const int traj0 = rb * TB;
+  const int co0 = ct * 64;
+  TRACE_STAMP(0);
+#ifdef TRACE_CONV_STAMPS
+  if (a.dbg && threadIdx.x == 0) {
+    a.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+    a.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+  }
+#endif
+
+  // ---- staging: thread handles float4 #(tid + 256 j) of the chunk -------------------------
+  // Buffer loads with a 32-bit byte offset: the descriptor's range check returns 0 for
+  // trajectories past `rows` (tail workgroup), so there is no per-load predicate.
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
+      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.in2 ? a.in2 : a.in), 0,
+      a.in2 ? (unsigned)((size_t)a.rows * a.in2_tstride * sizeof(float)) : 0u, 0x00020000);
+  const int nch1 = a.cin / CH;
+  const int nch = nch1 + a.cin2 / CH;
+  unsigned spk[NF4];            // (trajectory in tile) << 20 | float offset inside the chunk
+#pragma unroll
+  for (int j = 0; j < NF4; ++j) {
+    const int q = tid + 256 * j;
+    const int tr = q / G::F4_PER_TRAJ;
+    const int rem = q - tr * G::F4_PER_TRAJ;
+    spk[j] = q < G::F4_TOTAL ? ((unsigned)tr << 20) | (unsigned)(rem * 4) : 0xffffffffu;
+  }
+  f32x4 stg[NF4];
+  auto stage_load = [&](int ch) {
+    const bool second = ch >= nch1;
+    const int tstride = second ? a.in2_tstride : a.in_tstride;
+    const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
+                      traj0 * tstride;
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const unsigned off = spk[j] == 0xffffffffu
+                               ? 0xffffffffu     // out of range -> zeros
+                               : ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u;
+      auto v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0)
+                      : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+      stg[j] = __builtin_bit_cast(f32x4, v);
+    }
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+      const int q = tid + 256 * j;
+      if (q < G::F4_TOTAL) {
+        const int tr = q / G::F4_PER_TRAJ;
+        const int e0 = (q - tr * G::F4_PER_TRAJ) * 4;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u;
+          const int ci = e / L_IN;
+          const int i = e - ci * L_IN;
+          lds[(tr * LP + i * UP + PADL) * CHS + ci] = stg[j][u];
+        }
+      }
+    }
+  };
+
+  stage_load(0);
+  // halo / zero-stuffing positions are written once; data positions are the same for every chunk
+  if constexpr (UP == 1 && IN_STRIDE == 1 && TAPS == 1) {
+    // 1x1 conv: no halo, every position is overwritten by stage_write
+  } else if constexpr (UP == 1 && IN_STRIDE == 1) {
+    // every data position is overwritten by stage_write: only the TAPS-1 halo positions per
+    // trajectory need zeros
+    constexpr int HALO = LP - L_IN;                     // = TAPS - 1, PADL of them in front
+    constexpr int Q = CHS / 4;
+    for (int i = tid; i < TB * HALO * Q; i += 256) {
+      const int tr = i / (HALO * Q);
+      const int r = i - tr * (HALO * Q);
+      const int h = r / Q;
+      const int pos = tr * LP + (h < PADL ? h : L_IN + h);
+      reinterpret_cast<f32x4*>(lds)[pos * Q + (r - h * Q)] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+#pragma unroll 2
+    for (int i = tid; i < CHS * S / 4; i += 256)
+      reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // LDS image is [position][channel]; lane (row = lane&15, kq = lane>>4) reads the 4 channels
+  // 16m + 4kq .. +3 of its output row's input position with one ds_read_b128, and feeds element
+  // u to MFMA pass u (the host packs the weights in the matching k order)
+  int rowoff[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) {
+    int r = rt * 16 + (lane & 15);
+    int tr = r / L_OUT;
+    int l = r - tr * L_OUT;
+    rowoff[rt] = (tr * LP + l * IN_STRIDE) * CHS + (lane >> 4) * 4;
+  }
+  f32x4 acc[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const f32x4* wp = a.wp + ((size_t)(ct * 4 + wave) * a.nkb) * 64 + lane;
+  f32x4 bnext = *wp;
+  f32x4 bnext2 = a.nkb > 1 ? wp[64] : bnext;
+  int kdone = 0;
+
+  TRACE_STAMP(14);
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();            // previous chunk fully consumed (and zero fill done)
+    stage_write();
+    if (ch == 0) TRACE_STAMP(15);
+    if (ch + 1 < nch) stage_load(ch + 1);       // in flight during this chunk's K loop
+    __syncthreads();
+
+    // K loop over the staged chunk.  One ds_read_b128 per (row tile, k-block) supplies the A
+    // values of 4 MFMA passes; the read for the NEXT k-block is issued right after the last pass
+    // that consumes the register, i.e. 13 MFMAs (>400 cycles) ahead of its first use.
+    // Chunks of the second source contribute at the centre tap only.
+    if (ch == 0) TRACE_STAMP(1);
+    const bool second = ch >= nch1;
+    int kk = second ? PADL * KBPC : 0;
+    const int kk_end = second ? (PADL + 1) * KBPC : NKK;
+    int tap = second ? PADL : 0, kb = 0;
+    f32x4 av[NRT];
+    const float* lp = lds + tap * CHS;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(lp + rowoff[rt]);
+    for (; kk < kk_end; ++kk) {
+      const f32x4 b = bnext;
+      bnext = bnext2;
+      ++kdone;
+      wp += 64;
+      if (kdone + 1 < a.nkb) bnext2 = wp[64];
+      int kb2 = kb + 1, tap2 = tap;
+      if (kb2 == KBPC) { kb2 = 0; ++tap2; }
+      const float* lpn = lds + tap2 * CHS + kb2 * 16;
+      const bool more = kk + 1 < kk_end;
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][u], b[u], acc[rt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) {
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], b[3], acc[rt], 0, 0, 0);
+        if (more) av[rt] = *reinterpret_cast<const f32x4*>(lpn + rowoff[rt]);
+      }
+      lp = lpn;
+      kb = kb2;
+      tap = tap2;
+    }
+    if (ch < 4) TRACE_STAMP(2 + ch);
+  }
+
+  conv_epilogue<L_OUT, TB>(a, acc, lds, traj0, co0);
 }
 
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>

@@ -6,7 +6,7 @@
 #include <functional>
 #include <vector>
 
-#include "conv_kernels.h"
+#include "conv_bf3_kernels.h"
 
 namespace trace {
 
@@ -229,6 +229,8 @@ struct PackedConv {
   int chunk = 0;
   int nkb = 0;
   int cin2 = 0;        // channels of the appended centre-tap source
+  void* wb = nullptr;  // device, split-bf16 stream [cout/16][nsl][3][64] x 8 bf16 (null: fp32 kernel only)
+  int nsl = 0;
 };
 
 struct Block {
@@ -336,6 +338,52 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
   pc->chunk = chunk;
   pc->nkb = nkb;
   pc->cin2 = cin2;
+  // split-bf16 stream for conv_bf3_kernel: slices of 32 channels, chunk-major then tap, the second
+  // source appended; every weight as three bf16 terms h + m + l (round-to-nearest each)
+  if (cin_real % 32 == 0 && cin2 % 32 == 0) {
+    auto bf16_rne = [](float v) -> uint16_t {
+      uint32_t x;
+      memcpy(&x, &v, 4);
+      x += 0x7fffu + ((x >> 16) & 1u);
+      return (uint16_t)(x >> 16);
+    };
+    auto bf16_f = [](uint16_t b) -> float {
+      uint32_t x = (uint32_t)b << 16;
+      float v;
+      memcpy(&v, &x, 4);
+      return v;
+    };
+    const int nsl = taps * cin_real / 32 + cin2 / 32;
+    std::vector<uint16_t> hb((size_t)(cout / 16) * nsl * 3 * 64 * 8, 0);
+    for (int ct = 0; ct < cout / 16; ++ct) {
+      int sl = 0;
+      auto put = [&](int c0, int tap, bool second) {
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int ci = c0 + (lane >> 4) * 8 + j;
+            const int co = ct * 16 + (lane & 15);
+            const float v = second ? get2(ci, co) : get(tap, ci, co);
+            const uint16_t h = bf16_rne(v);
+            const float r = v - bf16_f(h);
+            const uint16_t m = bf16_rne(r);
+            const uint16_t l = bf16_rne(r - bf16_f(m));
+            const size_t base = (((size_t)ct * nsl + sl) * 3 * 64 + lane) * 8 + j;
+            hb[base] = h;
+            hb[base + 64 * 8] = m;
+            hb[base + 2 * 64 * 8] = l;
+          }
+        ++sl;
+      };
+      for (int c0 = 0; c0 < cin_real; c0 += 32)
+        for (int tap = 0; tap < taps; ++tap) put(c0, tap, false);
+      for (int c0 = 0; c0 < cin2; c0 += 32) put(c0, 0, true);
+    }
+    uint16_t* db = nullptr;
+    rc = upload(u, hb, &db);
+    if (rc) return rc;
+    pc->wb = db;
+    pc->nsl = nsl;
+  }
   return TRACE_OK;
 }
 
@@ -675,6 +723,36 @@ int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
   // zero-stuffed (transposed) convolutions multiply half of their taps by structural zeros
   if (kind == K_UP_F || kind == K_DOWN_B) a.alg_macs_per_pos *= 0.5;
   const int ch = a.chunk;
+  // split-bf16 kernel wherever the layer has a packed stream for it (stride-1 and zero-stuffed
+  // convs with input channels in multiples of 32); TRACE_CONV_FP32=1 forces the fp32-MFMA kernel
+  static const bool force_fp32 = [] {
+    const char* e = getenv("TRACE_CONV_FP32");
+    return e && e[0] == '1';
+  }();
+  if (a.wb && !force_fp32) {
+    switch (kind) {
+      case K_CONV5:
+        if (L_out == 52) return launch_conv_bf3<52, 1, 5, 2, 4>(a, st);
+        if (L_out == 26) return launch_conv_bf3<26, 1, 5, 2, 8>(a, st);
+        if (L_out == 13) return launch_conv_bf3<13, 1, 5, 2, 16>(a, st);
+        break;
+      case K_CONV1:
+        if (L_out == 52) return launch_conv_bf3<52, 1, 1, 0, 4>(a, st);
+        if (L_out == 26) return launch_conv_bf3<26, 1, 1, 0, 8>(a, st);
+        if (L_out == 13) return launch_conv_bf3<13, 1, 1, 0, 16>(a, st);
+        break;
+      case K_UP_F:
+        if (L_out == 26) return launch_conv_bf3<26, 2, 4, 2, 8>(a, st);
+        if (L_out == 52) return launch_conv_bf3<52, 2, 4, 2, 4>(a, st);
+        break;
+      case K_DOWN_B:
+        if (L_out == 52) return launch_conv_bf3<52, 2, 3, 1, 4>(a, st);
+        if (L_out == 26) return launch_conv_bf3<26, 2, 3, 1, 8>(a, st);
+        break;
+      default:
+        break;          // stride-2 convs: fp32 kernel below
+    }
+  }
   switch (kind) {
     case K_CONV5:
       if (L_out == 52 && ch == 64) return launch_conv<52, 1, 1, 5, 2, 4, 64>(a, st);
@@ -735,6 +813,8 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.rows = rows;
   a.alg_macs_per_pos = (double)w.cout * w.cin_real * w.taps + (double)w.cout * w.cin2;
   a.cin2 = w.cin2;     // the caller must point in2 at the second source (set_in2)
+  a.wb = w.wb;
+  a.nsl = w.nsl;
   return a;
 }
 
