@@ -14,8 +14,12 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtrace_hip.so")
 
 # (source, extra flags).  steps/guidance hold the op-exact elementwise chains: no FMA contraction.
+# unet.hip: no SLP vectorisation -- packed-fp32 VALU (v_pk_add_f32 ...) that the vectoriser forms from
+# the two-rows-per-thread GroupNorm statistics feeds the DPP butterfly, and on gfx950 a DPP read issued
+# shortly after a packed write saw stale lanes 48..63 (run-to-run differences at two workgroups per
+# CU, found with scripts/dbg_determinism.py / dbg_ws_diff.py); packed fp32 is also slower beside MFMAs.
 SOURCES = [
-    ("unet.hip", []),
+    ("unet.hip", ["-fno-slp-vectorize"]),
     ("steps.hip", ["-ffp-contract=off"]),
     ("guidance.hip", ["-ffp-contract=off"]),
 ]

@@ -249,7 +249,29 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
     if (ch < 4) TRACE_STAMP(2 + ch);
   }
 
+#ifdef BF3_DBG_SYNC
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+#endif
+#ifdef BF3_DBG_NOEPI
+  {
+    const int col = lane & 15, q = lane >> 4;
+    const int co = co0 + wave * 16 + col;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int r = rt * 16 + q * 4 + reg;
+        const int tr = r / L_OUT, l = r - tr * L_OUT;
+        if (traj0 + tr < a.rows)
+          a.out[(size_t)(traj0 + tr) * a.out_tstride + (size_t)(a.out_coff + co) * L_OUT + l] = acc[rt][reg];
+      }
+  }
+#elif defined(BF3_DBG_SEP)
+  conv_epilogue<L_OUT, TB>(a, acc, lds + 3 * PLANE / 4, traj0, co0);
+#else
   conv_epilogue<L_OUT, TB>(a, acc, lds, traj0, co0);
+#endif
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
@@ -286,13 +308,21 @@ int launch_conv_bf3(const ConvArgs& a_in, hipStream_t st) {
                 "conv(bf16x3): output / residual tensors must be 16-byte aligned per trajectory tile and "
                 "below 4 GiB (%d rows)", a.rows);
   TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
+#ifdef BF3_DBG_SEP
+  constexpr size_t lds_bytes = 3 * G::PLANE + G::EPI_BYTES;
+#elif defined(BF3_DBG_OCC1)
+  constexpr size_t lds_bytes = 100 * 1024;
+#elif defined(BF3_DBG_PAD)
+  constexpr size_t lds_bytes = 80 * 1024;
+#else
   constexpr size_t lds_bytes = G::LDS_BYTES;
   static_assert(lds_bytes <= 80 * 1024, "conv(bf16x3): LDS per workgroup too large for two per CU");
+#endif
   static bool attr_set = false;
   if (!attr_set) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes > 80 * 1024 ? 160 * 1024 : 80 * 1024));
     attr_set = true;
   }
   const int nrb = (a.rows + TB - 1) / TB;

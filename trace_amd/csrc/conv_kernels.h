@@ -117,6 +117,9 @@ __device__ __forceinline__ float dpp_add(float v, int ctrl_tag) {
 
 template <int NP>
 __device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
+  // keep a few idle issue slots between whatever produced v[] and the first cross-lane read (see the
+  // note on packed-fp32 producers in trace_amd/build.py)
+  asm volatile("s_nop 4");
   if (cg > 1) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) v[j] = dpp_add(v[j], 1);

@@ -729,7 +729,16 @@ int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
     const char* e = getenv("TRACE_CONV_FP32");
     return e && e[0] == '1';
   }();
-  if (a.wb && !force_fp32) {
+  // diagnostic: TRACE_BF3_MASK = bit mask over (kind * 3 + level) of the layers allowed on the bf16 pipe
+  static const long bf3_mask = [] {
+    const char* e = getenv("TRACE_BF3_MASK");
+    return e ? strtol(e, nullptr, 0) : -1L;
+  }();
+  const int level = L_out == 52 ? 0 : L_out == 26 ? 1 : 2;
+  static const int f_cin = getenv("TRACE_BF3_CIN") ? atoi(getenv("TRACE_BF3_CIN")) : 0;
+  static const int f_cout = getenv("TRACE_BF3_COUT") ? atoi(getenv("TRACE_BF3_COUT")) : 0;
+  if (a.wb && !force_fp32 && ((bf3_mask >> ((int)kind * 3 + level)) & 1) && (!f_cin || f_cin == a.cin) &&
+      (!f_cout || f_cout == a.cout)) {
     switch (kind) {
       case K_CONV5:
         if (L_out == 52) return launch_conv_bf3<52, 1, 5, 2, 4>(a, st);
