@@ -76,7 +76,7 @@ int trace_unet_cond_table(const trace_unet* u, const float* cond, int n_rows, fl
 int64_t trace_unet_workspace_bytes(const trace_unet* u, int rows, int save);
 
 /* One denoiser evaluation, TemporalMapUnet.forward (tbsim/models/temporal.py:117-142).
- *   x_in   (rows, in_channels padded to 48, horizon)  channel-major, as written by
+ *   x_in   (rows, in_channels padded to 64, horizon)  channel-major, as written by
  *          trace_map_query; pad channels must be zero
  *   cond_table (n_cond_rows, cond_width); row r uses table row r / rows_per_cond
  *   step   diffusion step t (same for all rows, tbsim/models/trace.py:738)

@@ -82,7 +82,8 @@ struct ConvArgs {
   int raw_coff;
   // split-bf16 weight stream (conv_bf3_kernels.h): [cout/16][nsl][3 planes][64 lanes] x 8 bf16, or null
   const void* wb;
-  int nsl;             // k-slices of 32 = taps * cin / 32 + cin2 / 32
+  int nsl;             // k-slices of 32 = taps * cin_b / 32 + cin2 / 32
+  int cin_b;           // input channels of the split-bf16 stream (cin_real rounded up to 32, zero weights)
   unsigned long long* dbg;   // diagnostic builds only (TRACE_CONV_STAMPS): 16 time stamps per workgroup
 };
 

@@ -231,6 +231,7 @@ struct PackedConv {
   int cin2 = 0;        // channels of the appended centre-tap source
   void* wb = nullptr;  // device, split-bf16 stream [cout/16][nsl][3][64] x 8 bf16 (null: fp32 kernel only)
   int nsl = 0;
+  int cin_b = 0;       // input channels of that stream: cin_real rounded up to 32 (zero weights)
 };
 
 struct Block {
@@ -340,7 +341,8 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
   pc->cin2 = cin2;
   // split-bf16 stream for conv_bf3_kernel: slices of 32 channels, chunk-major then tap, the second
   // source appended; every weight as three bf16 terms h + m + l (round-to-nearest each)
-  if (cin_real % 32 == 0 && cin2 % 32 == 0) {
+  if (cin2 % 32 == 0) {
+    const int cin_b = (cin_real + 31) / 32 * 32;
     auto bf16_rne = [](float v) -> uint16_t {
       uint32_t x;
       memcpy(&x, &v, 4);
@@ -353,7 +355,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
       memcpy(&v, &x, 4);
       return v;
     };
-    const int nsl = taps * cin_real / 32 + cin2 / 32;
+    const int nsl = taps * cin_b / 32 + cin2 / 32;
     std::vector<uint16_t> hb((size_t)(cout / 16) * nsl * 3 * 64 * 8, 0);
     for (int ct = 0; ct < cout / 16; ++ct) {
       int sl = 0;
@@ -362,7 +364,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
           for (int j = 0; j < 8; ++j) {
             const int ci = c0 + (lane >> 4) * 8 + j;
             const int co = ct * 16 + (lane & 15);
-            const float v = second ? get2(ci, co) : get(tap, ci, co);
+            const float v = second ? get2(ci, co) : (ci < cin_real ? get(tap, ci, co) : 0.f);
             const uint16_t h = bf16_rne(v);
             const float r = v - bf16_f(h);
             const uint16_t m = bf16_rne(r);
@@ -374,7 +376,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
           }
         ++sl;
       };
-      for (int c0 = 0; c0 < cin_real; c0 += 32)
+      for (int c0 = 0; c0 < cin_b; c0 += 32)
         for (int tap = 0; tap < taps; ++tap) put(c0, tap, false);
       for (int c0 = 0; c0 < cin2; c0 += 32) put(c0, 0, true);
     }
@@ -383,6 +385,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
     if (rc) return rc;
     pc->wb = db;
     pc->nsl = nsl;
+    pc->cin_b = cin_b;
   }
   return TRACE_OK;
 }
@@ -484,7 +487,7 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
                 (long long)trace_unet_param_count(cfg), (long long)n_params);
   trace_unet* u = new trace_unet();
   u->cfg = *cfg;
-  u->cin_pad = 48;
+  u->cin_pad = 64;     // 38 input channels padded to two 32-channel chunks (zeros)
   Cursor cur{params, n_params};
   const int emb = cfg->cond_dim + cfg->time_dim;
   const int td = cfg->time_dim;
@@ -738,7 +741,8 @@ int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
   static const int f_cin = getenv("TRACE_BF3_CIN") ? atoi(getenv("TRACE_BF3_CIN")) : 0;
   static const int f_cout = getenv("TRACE_BF3_COUT") ? atoi(getenv("TRACE_BF3_COUT")) : 0;
   if (a.wb && !force_fp32 && ((bf3_mask >> ((int)kind * 3 + level)) & 1) && (!f_cin || f_cin == a.cin) &&
-      (!f_cout || f_cout == a.cout)) {
+      (!f_cout || f_cout == a.cout) && !(a.cin_b != a.cin && getenv("TRACE_BF3_NOFIRST"))) {
+    a.cin = a.cin_b;     // the first layer's 38 channels: 64 on this path (48 on the fp32 one), zero weights
     switch (kind) {
       case K_CONV5:
         if (L_out == 52) return launch_conv_bf3<52, 1, 5, 2, 4>(a, st);
@@ -824,6 +828,7 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.cin2 = w.cin2;     // the caller must point in2 at the second source (set_in2)
   a.wb = w.wb;
   a.nsl = w.nsl;
+  a.cin_b = w.cin_b;
   return a;
 }
 

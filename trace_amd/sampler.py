@@ -22,7 +22,7 @@ from .guidance import DiffuserGuidance, verify_guidance_config_list
 from .schedule import Schedule
 from .unet_params import flatten_unet_params
 
-C_PAD = 48   # denoiser input channels (38) padded to a multiple of the MFMA k-block
+C_PAD = 64   # denoiser input channels (38) padded to two 32-channel MFMA k-slices (pad stays zero)
 
 
 class TraceSampler:
