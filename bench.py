@@ -177,7 +177,11 @@ def main():
         ms, nl, fl = C.c_double(), C.c_int64(), C.c_double()
         _cabi.check(L.trace_profile_end(C.byref(ms), C.byref(nl), C.byref(fl)), "trace_profile_end")
         achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        peak = 157.3
+        # The conv kernel computes fp32 results on the bf16 matrix pipe: every algorithmic multiply-add
+        # is 6 bf16 MFMA multiply-adds (exact 3-way operand split), so its MFMA
+        # roof in ALGORITHMIC FLOP/s is the dense bf16 peak / 6.  `achieved` counts algorithmic FLOPs.
+        bf16_peak, fp32_mfma_peak = 2500.0, 157.3
+        peak = bf16_peak / 6.0
         # HBM bytes per launch cannot be counted from inside this process: the value comes from the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, corrected as
         # MI355X_MICROARCH.md prescribes), null when that summary is absent.
@@ -186,8 +190,12 @@ def main():
         if os.path.exists(tpath):
             with open(tpath) as f:
                 traffic = float(json.load(f)["hbm_bytes_per_launch"])
-        roofline = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA implicit-GEMM conv)",
+        roofline = {"bound": "mfma",
+                    "kernel": "conv_bf3_kernel (fp32 implicit-GEMM conv as 6 bf16-MFMA terms per product, "
+                              "fp32 accumulate; a few stride-2 layers still on the fp32-MFMA conv_gemm_kernel)",
                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                    "peak_is": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA terms per algorithmic product",
+                    "frac_of_fp32_mfma_peak": achieved / fp32_mfma_peak,
                     "traffic": traffic, "launches": int(nl.value),
                     "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
                     "conv_ms_per_ddpm_step": ms.value / n_prof_steps}
@@ -200,7 +208,8 @@ def main():
             "metric": "guided trajectory samples/sec (100 DDPM steps, 52-step horizon)",
             "value": total / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (denoiser GEMMs: exact 3-way bf16 split on bf16 MFMA, f32 accumulate; everything else f32)",
             "data": "synthetic (seeded ORCA-style scenes, random-init orca_mixed weights)"
                     + ("; inputs in HOST memory, PCIe copy inside the timed region" if args.host_inputs else ""),
             "config": {"workload": args.workload, "agents_per_gpu": B, "samples_per_agent": N,

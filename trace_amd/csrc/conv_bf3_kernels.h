@@ -21,8 +21,11 @@
 //            version spent 62 % of its LDS cycles on bank conflicts, LDS 66 % busy).
 // B operand: weights split and packed on the host in fragment order [col tile][slice][plane][lane],
 //            streamed L2 -> VGPR two slices (one slice = one tap x 32 channels) ahead.
-// K loop   : fully unrolled over the taps of a chunk; the A fragments of row tile n+2 are requested
-//            while tile n multiplies (3 register stages), 6 MFMAs per (row tile, slice).
+// rows     : row tile rt = positions PPT rt .. of ALL trajectories of the workgroup (PPT = L / 13), so
+//            one base address serves every tile (+ immediates) and the 16 rows of a read are 16
+//            trajectories x positions at distinct slots (Bf3Geom::lp_pad); the epilogue's ROWMAP = 1
+// K loop   : fully unrolled over the taps of a chunk; the A fragments of row tile n+3 are requested
+//            while tile n multiplies (4 register stages), 6 MFMAs per (row tile, slice).
 #pragma once
 #include <cstdint>
 #include <type_traits>
@@ -62,7 +65,16 @@ struct Bf3Geom {
   static constexpr int CH = 32;                            // channels per chunk = one MFMA k-slice per tap
   static constexpr int R = TB * L_OUT;
   static constexpr int NRT = R / 16;
-  static constexpr int LP = (L_OUT - 1) + TAPS;            // staged positions per trajectory (stride 1)
+  static constexpr int PPT = L_OUT / NRT;                  // positions per row tile (4, 2, 1)
+  // Row tile rt = positions PPT rt .. + PPT - 1 of all TB trajectories (MFMA row i = trajectory * PPT +
+  // position offset), so the 16 rows of an LDS read sit at cells trajectory * LP + const: LP is the
+  // staged positions per trajectory, padded until those 16 cells fall into 16 different 16-byte
+  // slots modulo 16 (TB = 4: LP = 4 or 12 mod 16; TB = 8: LP / 2 odd; TB = 16: LP odd).
+  static constexpr int lp_pad(int lp) {
+    while (!(TB == 4 ? (lp % 16 == 4 || lp % 16 == 12) : TB == 8 ? (lp % 2 == 0 && (lp / 2) % 2 == 1) : lp % 2 == 1)) ++lp;
+    return lp;
+  }
+  static constexpr int LP = lp_pad((L_OUT - 1) + TAPS);
   static constexpr int S = TB * LP;
   static constexpr int L_IN = L_OUT / UP;
   static constexpr int SUB = (S * 16 + 255) / 256 * 256;   // bytes of one (plane, channel octet) array
@@ -72,7 +84,7 @@ struct Bf3Geom {
   static constexpr int NUT = (NU + 255) / 256;
   static constexpr size_t EPI_BYTES = ((size_t)R * 64 + (size_t)TB * 64 * 4) * sizeof(float);
   static constexpr size_t LDS_BYTES = (size_t)3 * PLANE > EPI_BYTES ? (size_t)3 * PLANE : EPI_BYTES;
-  static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0, "bad tile");
+  static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0 && PPT * NRT == L_OUT && PPT * TB == 16, "bad tile");
   static_assert(3 * PLANE < 65536, "LDS immediates must fit 16 bits");
 };
 
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
   // halo / zero-stuffing positions are written once; data positions are rewritten by every chunk
   if constexpr (UP == 1 && TAPS == 1) {
   } else if constexpr (UP == 1) {
-    constexpr int HALO = TAPS - 1;                       // PADL of them in front of the data
+    constexpr int HALO = LP - L_IN;                      // PADL cells in front of the data, the rest behind
     for (int i = tid; i < 12 * TB * HALO; i += 256) {    // (plane, octet) arrays x trajectories x halo cells
       const int arr = i / (TB * HALO);
       const int r0 = i - arr * (TB * HALO);
@@ -176,15 +188,18 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
       reinterpret_cast<u32x4v*>(ldsb)[i] = u32x4v{0u, 0u, 0u, 0u};
   }
 
-  // lane (row = lane & 15, kq = lane >> 4) reads channels 8 kq .. 8 kq + 7 of its output row's input
-  // position: one ds_read_b128 per plane
-  int rowoff[NRT];
+  // lane (MFMA row i = lane & 15, kq = lane >> 4) reads channels 8 kq .. 8 kq + 7 of the input position of
+  // its output row (trajectory i / PPT, position PPT rt + i % PPT): one ds_read_b128 per plane, and
+  // the row tiles differ by a constant (PPT cells)
+  constexpr int PPT = G::PPT;
+  const int rowoff0 = (((lane & 15) / PPT) * LP + (lane & 15) % PPT) * 16 + (lane >> 4) * SUB;
+  // one base per tap, made opaque: tile rt at tap t and tile rt - 1 at tap t + PPT read the same cell,
+  // and if the compiler can see that it merges the reads and keeps the fragments live (spills)
+  int tapoff[TAPS];
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) {
-    const int r = rt * 16 + (lane & 15);
-    const int tr = r / L_OUT;
-    const int l = r - tr * L_OUT;
-    rowoff[rt] = (tr * LP + l) * 16 + (lane >> 4) * SUB;
+  for (int t = 0; t < TAPS; ++t) {
+    tapoff[t] = rowoff0 + t * 16;
+    asm volatile("" : "+v"(tapoff[t]));
   }
   f32x4 acc[NRT];
 #pragma unroll
@@ -205,15 +220,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
   auto chunk_mma = [&](auto t0c, auto t1c, const int next) {
     constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
     constexpr int NT = (T1 - T0) * NRT;
-    bf16x8 av[3][3];
+    constexpr int NST = TAPS == 1 ? 3 : 4, DIST = NST - 1;               // A register stages / prefetch distance in tiles
+    bf16x8 av[NST][3];
     auto load_a = [&](int n, int stage) {
       const int tap = T0 + n / NRT, rt = n % NRT;
-      const char* p = ldsb + rowoff[rt] + tap * 16;
+      const char* p = ldsb + tapoff[tap] + rt * PPT * 16;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) av[stage][pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
     };
-    load_a(0, 0);
-    if (NT > 1) load_a(1, 1);
+#pragma unroll
+    for (int n = 0; n < DIST && n < NT; ++n) load_a(n, n);
     bf16x8 b[3];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
@@ -227,12 +243,12 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
           for (int p = 0; p < 3; ++p) bn2[p] = wp[192 + 64 * p];
         }
       }
-      if (n + 2 < NT) load_a(n + 2, (n + 2) % 3);
+      if (n + DIST < NT) load_a(n + DIST, (n + DIST) % NST);
       if (n == 1 && next >= 0) {
 #pragma unroll
         for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
       }
-      const int s = n % 3, rt = n % NRT;
+      const int s = n % NST, rt = n % NRT;
       f32x4 c = acc[rt];
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][2], b[0], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[2], c, 0, 0, 0);
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
     else if (ch == nch - 1) TRACE_STAMP(5);
   }
 
-  conv_epilogue<L_OUT, TB>(a, acc, lds, traj0, co0);
+  conv_epilogue<L_OUT, TB, 1>(a, acc, lds, traj0, co0);
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>

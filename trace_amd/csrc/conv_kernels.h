@@ -161,7 +161,11 @@ __device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
 //   E2  the whole tile is one flat stream              -> 128-bit LDS reads and global accesses
 // Residual operands are fetched into registers before anything else: their latency hides
 // under E0/E1 instead of serialising the store loop.
-template <int L_OUT, int TB>
+// ROWMAP says which output row MFMA row i of row tile rt is:
+//   0  rows in natural order:  r = 16 rt + i = trajectory * L_OUT + position        (conv_gemm_kernel)
+//   1  trajectory-major tiles: tile rt holds positions PPT rt .. PPT rt + PPT - 1 (PPT = L_OUT / 13) of
+//      all TB trajectories, i = trajectory * PPT + (position - PPT rt)               (conv_bf3_kernel)
+template <int L_OUT, int TB, int ROWMAP = 0>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB * L_OUT / 16], float* lds,
                                               const int traj0, const int co0) {
   constexpr int R = TB * L_OUT, NRT = R / 16;
@@ -217,7 +221,22 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
     int tr = 0, l = q * 4;                      // row r = rt*16 + q*4 + reg = tr*L_OUT + l
 #pragma unroll
     for (int rt = 0; rt < NRT; ++rt) {
-      if constexpr (L_OUT % 4 == 0) {           // a quad of rows never straddles two trajectories
+      if constexpr (ROWMAP == 1) {
+        constexpr int PPT = L_OUT / NRT;
+        static_assert(PPT * NRT == L_OUT && PPT * TB == 16 && (PPT == 1 || PPT == 2 || PPT == 4),
+                      "trajectory-major tiles need L_OUT = 13 PPT and TB = 16 / PPT");
+        f32x4 v = acc[rt];
+        v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv;
+        if constexpr (PPT == 4) {               // lane group q = trajectory, registers = 4 positions
+          *reinterpret_cast<f32x4*>(tcol + q * TILE + 4 * rt) = v;
+        } else if constexpr (PPT == 2) {        // registers 0,1 / 2,3 = two positions of trajectories 2q / 2q+1
+          *reinterpret_cast<float2*>(tcol + (2 * q) * TILE + 2 * rt) = float2{v[0], v[1]};
+          *reinterpret_cast<float2*>(tcol + (2 * q + 1) * TILE + 2 * rt) = float2{v[2], v[3]};
+        } else {                                // registers = trajectories 4q .. 4q+3, one position
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) tcol[(4 * q + reg) * TILE + rt] = v[reg];
+        }
+      } else if constexpr (L_OUT % 4 == 0) {    // a quad of rows never straddles two trajectories
         f32x4 v = acc[rt];
         v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv;
         *reinterpret_cast<f32x4*>(tcol + tr * TILE + l) = v;
