@@ -209,7 +209,10 @@ def main():
             "value": total / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (denoiser GEMMs: exact 3-way bf16 split on bf16 MFMA, f32 accumulate; everything else f32)",
+            "dtype": "f32",
+            "dtype_note": "fp32 results everywhere; the denoiser GEMMs evaluate each fp32 product as an exact 3-way "
+                          "bf16 operand split (6 bf16-MFMA terms, fp32 accumulate; rms error equal to the fp32 "
+                          "MFMA's, DESIGN.md section 5.1)",
             "data": "synthetic (seeded ORCA-style scenes, random-init orca_mixed weights)"
                     + ("; inputs in HOST memory, PCIe copy inside the timed region" if args.host_inputs else ""),
             "config": {"workload": args.workload, "agents_per_gpu": B, "samples_per_agent": N,
