@@ -240,10 +240,16 @@ class Diffuser(object):
     access).  Without a checkpoint on disk (none ship with the reference) it falls back to
     seeded random weights of the orca_mixed architecture when ``allow_random_init`` is set."""
 
-    def __init__(self, eval_config, device, ckpt_root_dir="checkpoints/", allow_random_init=False,
-                 seed=0):
+    def __init__(self, eval_config, device, ckpt_root_dir=None, allow_random_init=False,
+                 seed=0, random_map_encoder=False):
+        if ckpt_root_dir is None:
+            try:
+                ckpt_root_dir = self._get(eval_config, "ckpt_root_dir")
+            except (KeyError, AttributeError):
+                ckpt_root_dir = "checkpoints/"
         self.eval_config, self.device, self.ckpt_root_dir = eval_config, device, ckpt_root_dir
         self.allow_random_init, self.seed = allow_random_init, seed
+        self.random_map_encoder = random_map_encoder
 
     @staticmethod
     def _get(cfg, *path):
@@ -280,8 +286,18 @@ class Diffuser(object):
                 policy = DiffuserTrafficModel.load_from_checkpoint(ckpt, mc, self.device)
             elif self.allow_random_init:
                 mc = ModelConfig()
-                policy = DiffuserTrafficModel(mc, random_state_dict(mc, self.seed), self.device)
-                policy_cfg = {"algo": mc.to_algo_dict()}
+                sd = random_state_dict(mc, self.seed)
+                if self.random_map_encoder:
+                    from .map_encoder import random_map_encoder_state_dict
+                    sd.update(random_map_encoder_state_dict(mc.image_shape[0], mc.map_grid_feature_dim,
+                                                            mc.image_shape[1:], seed=self.seed))
+                policy = DiffuserTrafficModel(mc, sd, self.device)
+                # the parts of the experiment config the driver reads (scene_editor.py:61,107,227)
+                policy_cfg = {"algo": mc.to_algo_dict(),
+                              "env": {"rasterizer": {"include_hist": False, "num_sem_layers": mc.image_shape[0],
+                                                     "drivable_layers": None, "raster_size": mc.image_shape[1],
+                                                     "pixel_size": 1.0 / 12.0, "ego_center": [-0.5, 0.0],
+                                                     "no_map_fill_value": -1.0}}}
             else:
                 raise FileNotFoundError("no TRACE checkpoint found under %s" % self.ckpt_root_dir)
         pc = self._get(self.eval_config, "policy")
