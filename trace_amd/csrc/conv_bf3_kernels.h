@@ -82,7 +82,7 @@ struct Bf3Geom {
   static constexpr int NPOS = TB * L_IN;                   // data positions per chunk
   static constexpr int NU = NPOS * (CH / 8);               // staging units (position, channel octet)
   static constexpr int NUT = (NU + 255) / 256;
-  static constexpr size_t EPI_BYTES = ((size_t)R * 64 + (size_t)TB * 64 * 4) * sizeof(float);
+  static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float);      // the output tile (conv_epilogue)
   static constexpr size_t LDS_BYTES = (size_t)3 * PLANE > EPI_BYTES ? (size_t)3 * PLANE : EPI_BYTES;
   static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0 && PPT * NRT == L_OUT && PPT * TB == 16, "bad tile");
   static_assert(3 * PLANE < 65536, "LDS immediates must fit 16 bits");

@@ -367,9 +367,27 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
     return;
   }
 
+  // Raw conv outputs for the backward (clean guidance only): flat copy of the tile before it is
+  // normalised in place.
+  if (a.ysave) {
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.ysave, 0, (unsigned)((size_t)a.rows * a.cout * L_OUT * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int f = (tid + 256 * k) * 4;
+      const f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+      int rem2;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ry,
+                                             flat_off(k, a.cout * L_OUT, 0, rem2), 0, 0);
+    }
+    if (has_tab) __syncthreads();          // every flat read done before rows are rewritten
+  }
+
   // E1: one (trajectory, channel) row per thread and pass; lanes = the 64 channels, so the
-  // channels of a group are neighbouring lanes and the group reduction is a butterfly.
-  f32x4* tab = reinterpret_cast<f32x4*>(lds + R * 64);      // [TB][64] {scale, shift, add, -}
+  // channels of a group are neighbouring lanes and the group reduction is a butterfly.  The thread
+  // keeps its rows in registers, normalises / activates / adds the condition there and writes the
+  // finished rows back into the tile: no parameter table in LDS, so the tile alone (R x 64 floats =
+  // 52 KB) is the epilogue's footprint and three workgroups fit a CU.
   if (has_tab) {
     constexpr int NP = TB / 4;
     const int c = lane, co = co0 + c;
@@ -378,44 +396,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
     const float ptv = a.pc ? a.pt[co] : 0.f;
     const int cg = a.gn ? a.cg : 1;
     float add[NP], rmean[NP], m2[NP], gs[NP];
+    float v[NP][L_OUT];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int tg = min(traj0 + wave + 4 * j, a.rows - 1);
       add[j] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
       rmean[j] = 0.f;
       m2[j] = 0.f;
+      const float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
+      if constexpr (L_OUT % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < L_OUT / 4; ++i) {
+          f32x4 t = reinterpret_cast<const f32x4*>(row)[i];
+          v[j][4 * i] = t[0]; v[j][4 * i + 1] = t[1]; v[j][4 * i + 2] = t[2]; v[j][4 * i + 3] = t[3];
+        }
+      } else if constexpr (L_OUT % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < L_OUT / 2; ++i) {
+          float2 t = reinterpret_cast<const float2*>(row)[i];
+          v[j][2 * i] = t.x; v[j][2 * i + 1] = t.y;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) v[j][i] = row[i];
+      }
     }
+    float scale[NP], shift[NP];
     if (a.gn) {
       // exact two-level moments: row mean / centred sum of squares per (trajectory, channel)
       // row, then Chan's combination over the channels of the group
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        const float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
-        float v[L_OUT];
-        if constexpr (L_OUT % 4 == 0) {
-#pragma unroll
-          for (int i = 0; i < L_OUT / 4; ++i) {
-            f32x4 t = reinterpret_cast<const f32x4*>(row)[i];
-            v[4 * i] = t[0]; v[4 * i + 1] = t[1]; v[4 * i + 2] = t[2]; v[4 * i + 3] = t[3];
-          }
-        } else if constexpr (L_OUT % 2 == 0) {
-#pragma unroll
-          for (int i = 0; i < L_OUT / 2; ++i) {
-            float2 t = reinterpret_cast<const float2*>(row)[i];
-            v[2 * i] = t.x; v[2 * i + 1] = t.y;
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < L_OUT; ++i) v[i] = row[i];
-        }
         float sacc = 0.f;
 #pragma unroll
-        for (int i = 0; i < L_OUT; ++i) sacc += v[i];
+        for (int i = 0; i < L_OUT; ++i) sacc += v[j][i];
         const float rm = sacc * (1.f / (float)L_OUT);
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < L_OUT; ++i) {
-          const float d = v[i] - rm;
+          const float d = v[j][i] - rm;
           q = fmaf(d, d, q);
         }
         rmean[j] = rm;
@@ -439,8 +458,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
         const float mean = gs[j];
         const float var = gv[j] / (float)(cg * L_OUT);
         const float rstd = 1.f / sqrtf(var + 1e-5f);
-        const float scale = rstd * gam;
-        tab[tr * 64 + c] = f32x4{scale, bet - mean * scale, add[j], 0.f};
+        scale[j] = rstd * gam;
+        shift[j] = bet - mean * scale[j];
         if (a.stats && (c & (cg - 1)) == 0 && traj0 + tr < a.rows) {
           const int cgs = __builtin_ctz(cg);
           const size_t si = ((size_t)(traj0 + tr) * (a.cout >> cgs) + (co >> cgs)) * 2;
@@ -450,48 +469,45 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NP; ++j) tab[(wave + 4 * j) * 64 + c] = f32x4{1.f, 0.f, add[j], 0.f};
+      for (int j = 0; j < NP; ++j) { scale[j] = 1.f; shift[j] = 0.f; }
     }
     TRACE_STAMP(8);
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
+#pragma unroll
+      for (int i = 0; i < L_OUT; ++i) {
+        float z = fmaf(v[j][i], scale[j], shift[j]);
+        if (a.gn) z = mish_fast_f(z);
+        v[j][i] = z + add[j];
+      }
+      if constexpr (L_OUT % 4 == 0) {
+#pragma unroll
+        for (int i = 0; i < L_OUT / 4; ++i)
+          reinterpret_cast<f32x4*>(row)[i] = f32x4{v[j][4 * i], v[j][4 * i + 1], v[j][4 * i + 2], v[j][4 * i + 3]};
+      } else if constexpr (L_OUT % 2 == 0) {
+#pragma unroll
+        for (int i = 0; i < L_OUT / 2; ++i) reinterpret_cast<float2*>(row)[i] = float2{v[j][2 * i], v[j][2 * i + 1]};
+      } else {
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) row[i] = v[j][i];
+      }
+    }
     __syncthreads();
   }
   TRACE_STAMP(9);
 
-  // E2: flat pass -- normalise / activate / add / store, 4 consecutive outputs per access
+  // E2: flat pass -- + residual(s), store; 4 consecutive outputs per access
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
       a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-      a.ysave ? a.ysave : a.out, 0,
-      a.ysave ? (unsigned)((size_t)a.rows * a.cout * L_OUT * sizeof(float)) : 0u, 0x00020000);
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     const int f = (tid + 256 * k) * 4;
     f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
     int rem;
     const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
-    if (a.ysave) {
-      int rem2;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y),
-                                             ry, flat_off(k, a.cout * L_OUT, 0, rem2), 0, 0);
-    }
-    if (has_tab) {
-      const int tr = f / TILE;
-      const int c0 = rem / L_OUT;
-      const int l0 = rem - c0 * L_OUT;
-      const f32x4 t0 = tab[tr * 64 + c0];
-      f32x4 t1 = t0;
-      if constexpr (L_OUT % 4 != 0) t1 = tab[tr * 64 + min(c0 + 1, 63)];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool hi = (L_OUT % 4 != 0) && (l0 + i >= L_OUT);
-        const float sc = hi ? t1[0] : t0[0], sh = hi ? t1[1] : t0[1], ad = hi ? t1[2] : t0[2];
-        float z = fmaf(y[i], sc, sh);
-        if (a.gn) z = mish_fast_f(z);
-        y[i] = z + ad;
-      }
-    }
     y += rv[k];
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, y), ro, oo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
   }
   TRACE_STAMP(11);
 }
@@ -515,7 +531,7 @@ struct ConvGeom {
   static_assert((CHS / 4) % 2 == 1, "position stride must be an odd number of 16-byte slots");
   static constexpr int NQ = R * 64 / 4 / 256;              // output float4 per thread
   static_assert(R * 64 % 1024 == 0 && TB % 4 == 0, "output tile must split evenly over 256 threads");
-  static constexpr size_t EPI_FLOATS = (size_t)R * 64 + (size_t)TB * 64 * 4;   // tile + tables
+  static constexpr size_t EPI_FLOATS = (size_t)R * 64;                         // the output tile
   static constexpr size_t LDS_FLOATS = ((size_t)CHS * S > EPI_FLOATS) ? (size_t)CHS * S : EPI_FLOATS;
 };
 
