@@ -88,8 +88,11 @@ struct Bf3Geom {
   static_assert(3 * PLANE < 65536, "LDS immediates must fit 16 bits");
 };
 
+#ifndef TRACE_BF3_WGS
+#define TRACE_BF3_WGS 2           // resident workgroups per CU the register budget is sized for
+#endif
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
-__global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB>;
   constexpr int NRT = G::NRT, LP = G::LP, L_IN = G::L_IN, SUB = G::SUB, PLANE = G::PLANE;
   constexpr int NUT = G::NUT, NU = G::NU, NPOS = G::NPOS, CH = G::CH;
@@ -207,11 +210,19 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
 
   // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
   const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wb) + ((size_t)(ct * 4 + wave) * a.nsl) * 192 + lane;
+#ifndef TRACE_BF3_WPF
+#define TRACE_BF3_WPF 2           // weight slices in flight ahead of the one being multiplied
+#endif
+#ifndef TRACE_BF3_NST
+#define TRACE_BF3_NST 4           // A-fragment register stages (prefetch distance + 1)
+#endif
   bf16x8 bn1[3], bn2[3];
 #pragma unroll
   for (int p = 0; p < 3; ++p) bn1[p] = wp[64 * p];
+  if constexpr (TRACE_BF3_WPF >= 2) {
 #pragma unroll
-  for (int p = 0; p < 3; ++p) bn2[p] = a.nsl > 1 ? wp[192 + 64 * p] : bn1[p];
+    for (int p = 0; p < 3; ++p) bn2[p] = a.nsl > 1 ? wp[192 + 64 * p] : bn1[p];
+  }
   int sdone = 0;
 
   // one chunk's MFMAs over taps [T0, T1); the next chunk's activations (chunk `next`, -1 = none) are
@@ -220,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
   auto chunk_mma = [&](auto t0c, auto t1c, const int next) {
     constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
     constexpr int NT = (T1 - T0) * NRT;
-    constexpr int NST = TAPS == 1 ? 3 : 4, DIST = NST - 1;               // A register stages / prefetch distance in tiles
+    constexpr int NST = TAPS == 1 ? (TRACE_BF3_NST < 3 ? TRACE_BF3_NST : 3) : TRACE_BF3_NST, DIST = NST - 1;   // A register stages / prefetch distance in tiles
     bf16x8 av[NST][3];
     auto load_a = [&](int n, int stage) {
       const int tap = T0 + n / NRT, rt = n % NRT;
@@ -234,13 +245,24 @@ __global__ __launch_bounds__(256, 2) void conv_bf3_kernel(ConvArgs a) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       if (n % NRT == 0) {
+        if constexpr (TRACE_BF3_WPF >= 2) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
-        ++sdone;
-        wp += 192;
-        if (sdone + 1 < a.nsl) {
+          for (int p = 0; p < 3; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
+          ++sdone;
+          wp += 192;
+          if (sdone + 1 < a.nsl) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) bn2[p] = wp[192 + 64 * p];
+            for (int p = 0; p < 3; ++p) bn2[p] = wp[192 + 64 * p];
+          }
+        } else {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[p] = bn1[p];
+          ++sdone;
+          wp += 192;
+          if (sdone < a.nsl) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bn1[p] = wp[64 * p];
+          }
         }
       }
       if (n + DIST < NT) load_a(n + DIST, (n + DIST) % NST);
