@@ -36,7 +36,22 @@ WORKLOADS = {
     "cfg1_unguided": dict(scenes=1, agents=16, samples=20, guide=None, w=0.0, clean=False, dense=False),
     "cfg3_dense_collision": dict(scenes=1, agents=128, samples=20, guide="collision", w=0.0,
                                  clean=True, dense=True),
+    # BASELINE configs[3] per GPU at 8 GPUs: 64 scenes x 32 agents x 20 samples, guidance evaluated once on
+    # the final samples and used for selection only (guide_as_filter_only), scores all-gathered
+    "cfg4_filter_only": dict(scenes=64, agents=32, samples=20, guide="target_pos+collision", w=0.0,
+                             clean=True, dense=False, filter_only=True),
+    # BASELINE configs[4] per GPU at 8 GPUs: 128 scenes x 32 agents, closed loop on the device-resident
+    # environment, replanning every 10 frames for 100 frames, global_target_pos + collision guidance, 10 samples
+    "cfg5_closed_loop": dict(scenes=128, agents=32, samples=10, guide="closed_loop", w=0.0, clean=True,
+                             dense=False, closed_loop=True, n_step_action=10, sim_steps=100),
 }
+
+CLOSED_LOOP_HEURISTICS = [
+    {"name": "agent_collision", "weight": 1000.0, "params": {"num_disks": 1, "buffer_dist": 0.2}},
+    {"name": "map_collision", "weight": 10.0, "params": {"num_points_lw": [10, 10]}},
+    {"name": "global_target_pos", "weight": 10000.0,
+     "params": {"target_time": 100, "urgency": 0.7, "pref_speed": 1.25, "min_progress_dist": 0.5, "dt": 0.1}},
+]
 
 
 def build_inputs(cfg, wl, seed, device):
@@ -47,6 +62,9 @@ def build_inputs(cfg, wl, seed, device):
         guidance = syn.target_pos_guidance(batch, aps, weight=30000.0, seed=seed)
     elif wl["guide"] == "collision":
         guidance = syn.collision_guidance(aps, agent_weight=1000.0, map_weight=10.0, num_disks=1)
+    elif wl["guide"] == "target_pos+collision":
+        guidance = syn.merge_guidance(syn.target_pos_guidance(batch, aps, weight=30000.0, seed=seed),
+                                      syn.collision_guidance(aps, agent_weight=1000.0, map_weight=10.0, num_disks=1))
     if device is not None:
         batch = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch.items()}
     return aps, batch, guidance
@@ -124,26 +142,55 @@ def main():
     wl = dict(WORKLOADS[args.workload])
     if args.scenes is not None:
         wl["scenes"] = args.scenes
-    aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, None if args.host_inputs else device)
     N = wl["samples"]
-    B = sum(aps)
-    M = B * N
-
-    model = DiffuserTrafficModel(cfg, sd, device)
-    policy = PolicyWrapper.wrap_controller(model, num_action_samples=N, class_free_guide_w=wl["w"],
-                                           guide_as_filter_only=False, guide_with_gt=False,
-                                           guide_clean=wl["clean"])
-    if guidance is not None:
-        model.set_guidance(guidance, batch)
     gen = torch.Generator(device=device).manual_seed(7 + rank)
+    calls_per_step = 1
+    if wl.get("closed_loop"):
+        # the replanning loop: device-resident environment -> observation -> sampler -> step, scenes of
+        # this rank only (scene ids offset by rank so every rank simulates different scenes)
+        from trace_amd.map_encoder import random_map_encoder_state_dict
+        from trace_amd.policy import RolloutWrapper
+        from trace_amd.scene_edit import compute_heuristic_guidance, guided_rollout
+        from trace_amd.sim_env import SceneBatchEnv
+        aps = [wl["agents"]] * wl["scenes"]
+        B = sum(aps)
+        M = B * N
+        sd = dict(sd)
+        sd.update(random_map_encoder_state_dict(cfg.image_shape[0], cfg.map_grid_feature_dim, cfg.image_shape[1:], seed=0))
+        model = DiffuserTrafficModel(cfg, sd, device)
+        policy = PolicyWrapper.wrap_controller(model, num_action_samples=N, class_free_guide_w=wl["w"],
+                                               guide_as_filter_only=False, guide_with_gt=False,
+                                               guide_clean=wl["clean"])
+        env = SceneBatchEnv(cfg, aps, device=device, seed=100 + rank, num_simulation_steps=wl["sim_steps"])
+        rollout = RolloutWrapper(agents_policy=policy)
+        scene_ids = list(range(len(aps)))
+        guidance = compute_heuristic_guidance(CLOSED_LOOP_HEURISTICS, env, scene_ids, None)
+        calls_per_step = wl["sim_steps"] // wl["n_step_action"]
 
-    def one_step(i):
-        action, info = policy.get_action(batch, step_index=i, generator=gen, use_graph=args.graph)
-        scores = info.get("guide_scores")
-        if scores is None:
-            scores = torch.zeros(B, N, device=device)
-        # the path's one exchange step (RCCL all-gather; a no-op on one GPU)
-        return gather_actions(action.positions, action.yaws, scores, info["act_idx"])
+        def one_step(i):
+            stats, _ = guided_rollout(env, rollout, model, n_step_action=wl["n_step_action"],
+                                      guidance_config=guidance, scene_indices=scene_ids,
+                                      horizon=wl["sim_steps"], policy_kwargs={"generator": gen})
+            obs = env.get_observation()["agents"]
+            return (obs["centroid"], stats)
+    else:
+        aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, None if args.host_inputs else device)
+        B = sum(aps)
+        M = B * N
+        model = DiffuserTrafficModel(cfg, sd, device)
+        policy = PolicyWrapper.wrap_controller(model, num_action_samples=N, class_free_guide_w=wl["w"],
+                                               guide_as_filter_only=bool(wl.get("filter_only")), guide_with_gt=False,
+                                               guide_clean=wl["clean"])
+        if guidance is not None:
+            model.set_guidance(guidance, batch)
+
+        def one_step(i):
+            action, info = policy.get_action(batch, step_index=i, generator=gen, use_graph=args.graph)
+            scores = info.get("guide_scores")
+            if scores is None:
+                scores = torch.zeros(B, N, device=device)
+            # the path's one exchange step (RCCL all-gather; a no-op on one GPU)
+            return gather_actions(action.positions, action.yaws, scores, info["act_idx"])
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -166,7 +213,7 @@ def main():
     assert bool(torch.isfinite(out[0]).all()), "non-finite plan"
 
     roofline = None
-    if not args.no_roofline and rank == 0:
+    if not args.no_roofline and rank == 0 and not wl.get("closed_loop"):
         # dominant kernel = conv_gemm_kernel (denoiser forward + input-VJP): per-launch HIP events on
         # the launch stream over a short profiled stretch of the same workload
         L = _cabi.lib()
@@ -203,7 +250,7 @@ def main():
         dist.barrier()
 
     if rank == 0:
-        total = M * world * args.steps
+        total = M * world * args.steps * calls_per_step
         res = {
             "metric": "guided trajectory samples/sec (100 DDPM steps, 52-step horizon)",
             "value": total / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
@@ -219,11 +266,13 @@ def main():
                        "trajectories_per_gpu": M, "ddpm_steps": cfg.n_diffusion_steps,
                        "horizon": cfg.horizon, "class_free_guide_w": wl["w"],
                        "guidance": wl["guide"], "guide_clean": wl["clean"], "hip_graph": bool(args.graph),
+                       "guide_as_filter_only": bool(wl.get("filter_only")),
+                       "sampling_calls_per_step": calls_per_step,
                        "parallelism": "scenes sharded over %d GPU(s), all-gather of scores/plans" % world},
         }
         if roofline is not None:
             res["roofline"] = roofline
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not wl.get("closed_loop"):
             res["cpu_baseline"] = cpu_baseline(cfg, sd, args.workload)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -109,3 +109,38 @@ def test_closed_loop_replan_matches_oracle_on_env_observation():
     assert bool(torch.isfinite(got).all())
     err = float(((got - ref["pred_traj"]).abs() / (1 + ref["pred_traj"].abs())).max())
     assert err < 1e-4, err
+
+
+def test_composer_loads_lightning_checkpoint(tmp_path):
+    """``Diffuser(eval_cfg, device).get_policy()`` on a checkpoint directory laid out like the
+    reference's (``<ckpt_dir>/run/checkpoints/iter*.ckpt`` + ``config.json``; ``ema_policy.*`` keys):
+    same plan as the model built directly from the state_dict."""
+    from trace_amd import synthetic as syn
+    from trace_amd.config import ModelConfig
+    from trace_amd.eval_config import SceneEditingConfig, finalize_eval_config
+    from trace_amd.policy import Diffuser, DiffuserTrafficModel, PolicyWrapper
+    from trace_amd.weights import random_state_dict
+
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 5)
+    run = tmp_path / "ckpt" / "orca_mixed" / "run0"
+    (run / "checkpoints").mkdir(parents=True)
+    torch.save({"epoch": 3, "state_dict": {**{"ema_policy." + k: v for k, v in sd.items()},
+                                           **{"nets.policy." + k: v + 1 for k, v in sd.items()}}},
+               run / "checkpoints" / "iter40000_ep3.ckpt")
+    (run / "config.json").write_text(json.dumps(
+        {"algo": cfg.to_algo_dict(), "env": {"rasterizer": {"include_hist": False, "num_sem_layers": 2,
+                                                            "raster_size": 224}}}))
+    ev = finalize_eval_config(SceneEditingConfig(), policy_ckpt_dir=str(tmp_path / "ckpt" / "orca_mixed"),
+                              policy_ckpt_key="iter40000")
+    policy, exp_cfg = Diffuser(ev, "cuda:0").get_policy()
+    assert exp_cfg["algo"]["horizon"] == 52
+    aps = [3, 2]
+    batch = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in syn.make_batch(cfg, aps, seed=2).items()}
+    init, steps = syn.make_noise(cfg, sum(aps), 10, seed=1)
+    a1, _ = policy.get_action(batch, step_index=0, noise_init=init, noise_steps=steps)
+    direct = PolicyWrapper.wrap_controller(DiffuserTrafficModel(cfg, sd, "cuda:0"), num_action_samples=10,
+                                           class_free_guide_w=0.0, guide_as_filter_only=False,
+                                           guide_with_gt=False, guide_clean=True)
+    a2, _ = direct.get_action(batch, step_index=0, noise_init=init, noise_steps=steps)
+    assert torch.equal(a1.positions, a2.positions) and torch.equal(a1.yaws, a2.yaws)

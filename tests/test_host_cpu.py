@@ -188,3 +188,42 @@ def test_compat_package_exposes_the_reference_import_paths():
         sys.path.remove(compat)
         for m in [m for m in sys.modules if m == "tbsim" or m.startswith("tbsim.")]:
             del sys.modules[m]
+
+
+def test_get_checkpoint_layout(tmp_path):
+    """Checkpoint discovery as the reference's get_checkpoint (experiment_utils.py:39-80) and the
+    Lightning state_dict prefixes (algos.py:54,96)."""
+    import json
+    import torch
+    from trace_amd.config import ModelConfig
+    from trace_amd.policy import get_checkpoint, modality_image_shape
+    from trace_amd.weights import extract_policy_state_dict, random_state_dict
+
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 3)
+    run = tmp_path / "trace" / "orca_mixed" / "run0"
+    (run / "checkpoints").mkdir(parents=True)
+    ck = {"epoch": 1, "state_dict": {**{"ema_policy." + k: v for k, v in sd.items()},
+                                     **{"nets.policy." + k: v * 2 for k, v in sd.items()}}}
+    torch.save(ck, run / "checkpoints" / "iter40000_ep1_valLoss0.50.ckpt")
+    torch.save(ck, run / "checkpoints" / "iter20000_ep0_valLoss0.70.ckpt")
+    exp = {"algo": cfg.to_algo_dict(), "env": {"rasterizer": {"include_hist": False, "num_sem_layers": 7,
+                                                              "raster_size": 224}}}
+    (run / "config.json").write_text(json.dumps(exp))
+    ckpt, cfgp = get_checkpoint("iter40000", str(tmp_path / "trace" / "orca_mixed"))
+    assert ckpt.endswith("iter40000_ep1_valLoss0.50.ckpt") and cfgp.endswith("run0/config.json")
+    with pytest.raises(FileNotFoundError):
+        get_checkpoint("iter99999", str(tmp_path / "trace"))
+    with pytest.raises(AssertionError):
+        get_checkpoint("iter", str(tmp_path / "trace"))
+    loaded = torch.load(ckpt, map_location="cpu", weights_only=True)["state_dict"]
+    ema = extract_policy_state_dict(loaded, use_ema=True)
+    raw = extract_policy_state_dict(loaded, use_ema=False)
+    assert list(ema) == list(sd) and all(torch.equal(ema[k], sd[k]) for k in sd)
+    assert all(torch.equal(raw[k], sd[k] * 2) for k in sd)
+    mc = ModelConfig.from_algo_dict(json.loads((run / "config.json").read_text())["algo"],
+                                    image_shape=modality_image_shape(exp))
+    assert mc.image_shape == (7, 224, 224) and mc.unet_dims == cfg.unet_dims and mc.norm_div == cfg.norm_div
+    assert modality_image_shape({"algo": {"history_num_frames": 30},
+                                 "env": {"rasterizer": {"include_hist": True, "num_sem_layers": 2,
+                                                        "raster_size": 100}}}) == (33, 100, 100)

@@ -123,7 +123,8 @@ class RolloutWrapper(object):
             if p is not None:
                 p.eval()
 
-    def get_action(self, obs, step_index):
+    def get_action(self, obs, step_index, **agents_kwargs):
+        """``agents_kwargs`` (not in the reference) reach the agents policy: noise injection."""
         ego = ego_info = agents = agents_info = None
         with torch.no_grad():
             if self.ego_policy is not None:
@@ -132,7 +133,8 @@ class RolloutWrapper(object):
                 ego, ego_info = self.ego_policy.get_action(obs["ego"], step_index=step_index, **kw)
             if self.agents_policy is not None:
                 assert obs["agents"] is not None
-                agents, agents_info = self.agents_policy.get_action(obs["agents"], step_index=step_index)
+                agents, agents_info = self.agents_policy.get_action(obs["agents"], step_index=step_index,
+                                                                    **agents_kwargs)
         return RolloutAction(ego, ego_info, agents, agents_info)
 
 
@@ -233,6 +235,33 @@ class DiffuserTrafficModel(object):
         return action, info
 
 
+def get_checkpoint(ckpt_key, ckpt_dir):
+    """Checkpoint and config paths inside ``ckpt_dir`` (experiment_utils.py:39-80): the one ``*.ckpt``
+    anywhere below it whose path contains ``ckpt_key`` (``FileNotFoundError`` for none,
+    ``AssertionError`` for several) and the first ``config.json`` below it, else the parent's."""
+    import glob
+    assert ckpt_dir is not None
+    ckpts = [p for p in glob.glob(ckpt_dir + "/**/*.ckpt", recursive=True) if str(ckpt_key) in p]
+    if len(ckpts) == 0:
+        raise FileNotFoundError("Cannot find checkpoint in {} with key {}".format(ckpt_dir, ckpt_key))
+    assert len(ckpts) == 1, "More than one checkpoint found {}".format(ckpts)
+    cfgs = sorted(glob.glob(ckpt_dir + "/**/config.json", recursive=True)) or glob.glob(ckpt_dir + "/../config.json")
+    if len(cfgs) == 0:
+        raise FileNotFoundError("no config.json in or next to {}".format(ckpt_dir))
+    return ckpts[0], cfgs[0]
+
+
+def modality_image_shape(exp_cfg):
+    """(C, H, W) of the rasterised map input from the training config
+    (trajdata_utils.py:333-339: history layers when ``include_hist`` + semantic layers)."""
+    try:
+        r = exp_cfg["env"]["rasterizer"]
+        hist = (int(exp_cfg["algo"]["history_num_frames"]) + 1) if r.get("include_hist", False) else 0
+        return (hist + int(r["num_sem_layers"]), int(r["raster_size"]), int(r["raster_size"]))
+    except (KeyError, TypeError):
+        return (2, 224, 224)
+
+
 class Diffuser(object):
     """Policy composer selected by ``eval_cfg.eval_class`` (policy_composers.py:27-57).
     ``eval_config`` needs ``.policy.{num_action_samples, class_free_guide_w, guide_as_filter_only,
@@ -263,17 +292,18 @@ class Diffuser(object):
             ckpt_key = self._get(self.eval_config, "ckpt", "policy", "ckpt_key")
         except (KeyError, AttributeError):
             return None, None
-        root = os.path.join(self.ckpt_root_dir, ckpt_dir) if ckpt_dir else None
-        if not root or not os.path.isdir(root):
+        if not ckpt_dir:
             return None, None
-        ckpt = cfg = None
-        for dirpath, _, files in os.walk(root):
-            for f in files:
-                if f.endswith(".ckpt") and ckpt_key in f:
-                    ckpt = os.path.join(dirpath, f)
-                if f == "config.json":
-                    cfg = os.path.join(dirpath, f)
-        return ckpt, cfg
+        # the reference passes ckpt_dir as given (policy_composers.py:36-40); a path relative to
+        # ckpt_root_dir is accepted as well
+        for root in (ckpt_dir, os.path.join(self.ckpt_root_dir, ckpt_dir)):
+            if os.path.isdir(root):
+                try:
+                    return get_checkpoint(ckpt_key, root)
+                except FileNotFoundError:
+                    if not self.allow_random_init:
+                        raise
+        return None, None
 
     def get_policy(self, policy=None):
         policy_cfg = None
@@ -282,7 +312,7 @@ class Diffuser(object):
             if ckpt is not None and cfg_path is not None:
                 with open(cfg_path) as f:
                     policy_cfg = json.load(f)
-                mc = ModelConfig.from_algo_dict(policy_cfg["algo"])
+                mc = ModelConfig.from_algo_dict(policy_cfg["algo"], image_shape=modality_image_shape(policy_cfg))
                 policy = DiffuserTrafficModel.load_from_checkpoint(ckpt, mc, self.device)
             elif self.allow_random_init:
                 mc = ModelConfig()
