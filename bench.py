@@ -163,6 +163,12 @@ def main():
                                                guide_clean=wl["clean"])
         env = SceneBatchEnv(cfg, aps, device=device, seed=100 + rank, num_simulation_steps=wl["sim_steps"])
         rollout = RolloutWrapper(agents_policy=policy)
+        _inner_get_action = rollout.get_action
+
+        def _get_action_with_progress(obs, step_index, **kw):      # a long run must keep printing
+            print("[bench] replanning at frame %d" % step_index, file=sys.stderr, flush=True)
+            return _inner_get_action(obs, step_index, **kw)
+        rollout.get_action = _get_action_with_progress
         scene_ids = list(range(len(aps)))
         guidance = compute_heuristic_guidance(CLOSED_LOOP_HEURISTICS, env, scene_ids, None)
         calls_per_step = wl["sim_steps"] // wl["n_step_action"]

@@ -400,6 +400,44 @@ class AgentCollision:                                  # guidance_loss.py:202-33
         return pen[mask] if mask is not None else pen
 
 
+class SocialGroup:                                     # guidance_loss.py:744-814
+    """Members of a group keep `social_dist` to one assigned neighbour each.  The reference draws
+    torch.randint / torch.rand inside forward (:803-804); `draw` = (randint (T*N, G, 1), rand (T*N, G))
+    injects them, else they are drawn here in the same order."""
+
+    def __init__(self, leader_idx=0, social_dist=1.5, cohesion=0.8):
+        assert 0.0 <= cohesion <= 1.0
+        self.leader_idx, self.social_dist, self.p = leader_idx, social_dist, cohesion
+        self.draw = None
+
+    def __call__(self, x, batch, mask):
+        wfa = batch["world_from_agent"]
+        pos, yaw = x[..., :2], x[..., 3:4]
+        idx = torch.arange(pos.shape[0])
+        if mask is not None:
+            wfa, pos, yaw, idx = wfa[mask], pos[mask], yaw[mask], idx[mask]
+        wp, _ = agents_to_world(pos, yaw, wfa)
+        lead = (idx == self.leader_idx)[:, None, None, None].expand_as(wp)   # batch index vs leader_idx: as the reference
+        wp = torch.where(lead, wp.detach(), wp)
+        G, N, T, _ = wp.shape
+        flat = wp.transpose(0, 2).reshape(T * N, G, 2)
+        dist = torch.cdist(flat, flat)
+        eye = torch.eye(G).unsqueeze(0).expand_as(dist)
+        dist = torch.where(eye.bool(), float("inf") * eye, dist)
+        nearest = torch.argmin(dist, dim=-1)
+        choices = torch.arange(G)[None].expand(G, G).masked_select(~torch.eye(G, dtype=torch.bool)).view(G, G - 1)
+        choices = choices.unsqueeze(0).expand(T * N, G, G - 1)
+        if self.draw is not None:
+            ri, u = self.draw
+        else:
+            ri = torch.randint(0, G - 1, (T * N, G, 1))
+            u = torch.rand((T * N, G))
+        rand_nb = torch.gather(choices, 2, ri)[:, :, 0]
+        nb = torch.where(u < self.p, rand_nb, nearest)
+        d = torch.gather(dist, 2, nb.unsqueeze(-1))[..., 0].reshape(T, N, G).transpose(0, 2)
+        return torch.mean((d - self.social_dist) ** 2, dim=-1)
+
+
 class MapCollision:                                    # guidance_loss.py:341-464
     def __init__(self, num_points_lw=(10, 10)):
         self.local = torch.cartesian_prod(torch.linspace(-0.5, 0.5, num_points_lw[0]),
@@ -500,7 +538,7 @@ GUIDANCE = {                                           # guidance_loss.py:853-86
     "target_speed": TargetSpeed, "agent_collision": AgentCollision, "map_collision": MapCollision,
     "target_pos_at_time": TargetPosAtTime, "target_pos": TargetPos,
     "global_target_pos_at_time": GlobalTargetPosAtTime, "global_target_pos": GlobalTargetPos,
-    "min_speed": MinSpeed,
+    "min_speed": MinSpeed, "social_group": SocialGroup,
 }
 
 

@@ -281,3 +281,76 @@ def test_free_running_sample_vs_reference_golden(name):
         idx = out["guidance_plan"].choose_action(out["guidance_layer_losses"]).cpu().numpy()
         if not chaotic:
             assert np.array_equal(idx, gold["act_idx"]), (idx, gold["act_idx"])
+
+
+def test_social_group_value_and_grad(env):
+    """SocialGroupLoss kernels against the reference's golden (loss per agent and gradient) with the
+    reference's random neighbour draws injected; then the device-drawn path against the oracle fed the
+    same picks."""
+    from oracle.gen_golden_social import social_configs
+    from trace_amd.guidance import DiffuserGuidance
+    cfg, aps, batch = env["cfg"], env["aps"], env["batch"]
+    gold = dict(np.load(os.path.join(GOLDEN, "social_group.npz")))
+    traj0 = torch.tensor(dict(np.load(os.path.join(GOLDEN, "components.npz")))["loss/traj"])
+    B, N, T = traj0.shape[:3]
+    td = traj0.reshape(B * N, T, 6).to(DEV).contiguous()
+    for name, cfgs in social_configs().items():
+        plan = DiffuserGuidance(cfgs).build_plan(batch, N, T, DEV)
+        plan.social_tape = {k[len(name) + len("/randint/"):]: (torch.tensor(gold[k]),
+                                                              torch.tensor(gold[k.replace("/randint/", "/rand/")]))
+                            for k in gold if k.startswith(name + "/randint/")}
+        gt = torch.zeros(B * N, T, 6, device=DEV)
+        losses = plan.guide_losses(plan.evaluate(td, gt, None))
+        for k in plan.social_tape:
+            want = torch.tensor(gold["%s/per/%s" % (name, k)])
+            got = losses[k].cpu()
+            assert torch.equal(torch.isnan(got), torch.isnan(want)), (name, k)
+            assert _rel(torch.nan_to_num(got), torch.nan_to_num(want)) < 1e-5, (name, k)
+        gref = torch.tensor(gold[name + "/grad"])
+        scale = float(gref.abs().max())
+        err = float((gt.cpu().reshape(B, N, T, 6) - gref).abs().max()) / scale
+        assert scale > 0 and err < 2e-5, (name, err)
+    # device-drawn neighbours: finite, and the leader never receives a gradient
+    cfgs = social_configs()["mixed"]
+    plan = DiffuserGuidance(cfgs).build_plan(batch, N, T, DEV)
+    plan.generator = torch.Generator(device=DEV).manual_seed(3)
+    gt = torch.zeros(B * N, T, 6, device=DEV)
+    ll = plan.evaluate(td, gt, None)
+    g = gt.reshape(B, N, T, 6)
+    assert bool(torch.isfinite(g).all()) and bool(torch.isfinite(ll[0]).all())
+    assert float(g[0].abs().max()) == 0.0 and float(g[3].abs().max()) == 0.0      # leaders (batch idx 0, 3)
+    assert float(g[1].abs().max()) > 0 and float(g[4].abs().max()) > 0
+    assert float(g[..., 2:].abs().max()) == 0.0                                    # positions only
+
+
+def test_sampler_with_social_group_guidance(env):
+    """Clean-guided sampling steps with social_group + target_pos guidance: HIP sampler vs CPU oracle
+    with the same (static) neighbour draws injected on both sides."""
+    from oracle.gen_golden_social import social_configs
+    from trace_amd.sampler import TraceSampler
+    cfg, aps, batch, sd = env["cfg"], env["aps"], env["batch"], env["sd"]
+    gold = dict(np.load(os.path.join(GOLDEN, "social_group.npz")))
+    guidance = syn.merge_guidance(social_configs()["mixed"], syn.target_pos_guidance(batch, aps, weight=300.0, seed=5))
+    tape = {k[len("mixed/randint/"):]: (torch.tensor(gold[k]), torch.tensor(gold[k.replace("/randint/", "/rand/")]))
+            for k in gold if k.startswith("mixed/randint/")}
+    N, n_steps = 3, 10
+    init, steps = syn.make_noise(cfg, sum(aps), N, seed=9)
+    s = TraceSampler(cfg, sd, "cuda:0")
+    s.set_guidance(guidance, batch)
+    s.current_guidance.social_tape = tape
+    out = s(batch, num_samp=N, class_free_guide_w=0.0, guide_clean=True, noise_init=init, noise_steps=steps,
+            n_steps=n_steps, return_guidance_losses=True)
+    torch.cuda.synchronize()
+    o = orc.OracleSampler(cfg, sd)
+    o.set_guidance(guidance)
+    for si, cur in enumerate(o.guidance.scenes):
+        for gi, (gname, _, _, fn) in enumerate(cur):
+            if gname == "social_group":
+                fn.draw = tape["%s_scene_%03d_%02d" % (gname, si, gi)]
+    ref = o.sample(batch, N, 0.0, True, True, noise_init=init, noise_steps=steps, n_steps=n_steps,
+                   return_diffusion=False)
+    got = out["pred_traj_scaled"].cpu()
+    err = float(((got - ref["pred_traj"]).abs() / (1 + ref["pred_traj"].abs())).max())
+    assert err < 1e-4, err
+    gl = out["predictions"]["guide_losses"]
+    assert any(k.startswith("social_group") for k in gl.keys())

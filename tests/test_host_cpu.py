@@ -56,7 +56,7 @@ def test_guidance_config_checks_mirror_the_reference():
     with pytest.raises(AssertionError):                      # :79 unknown name
         GuidanceConfig.from_dict(dict(ok, name="nope"))
     with pytest.raises(NotImplementedError):
-        GuidanceConfig.from_dict(dict(ok, name="social_group"))
+        GuidanceConfig.from_dict(dict(ok, name="amp_value"))
     with pytest.raises(AssertionError):
         verify_guidance_config_list([])
     assert verify_guidance_config_list([[], [ok]]) and not verify_guidance_config_list([[], []])

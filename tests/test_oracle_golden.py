@@ -130,3 +130,27 @@ def test_sampler_end_to_end(name):
         for k, v in s["guide_losses"].items():
             _close(v, gold["guide_loss/" + k], 1e-4, 1e-6)
         assert np.array_equal(res["act_idx"].numpy(), gold["act_idx"])
+
+
+def test_social_group_vs_reference_golden(setup):
+    """SocialGroupLoss (guidance_loss.py:744-814) with the reference's own torch.randint / torch.rand
+    draws injected (tests/golden/social_group.npz, written by oracle/gen_golden_social.py)."""
+    from oracle.gen_golden_social import social_configs
+    cfg, sd, aps, batch = setup
+    gold = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "social_group.npz")))
+    traj0 = torch.tensor(dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "components.npz")))["loss/traj"])
+    for name, cfgs in social_configs().items():
+        guid = orc.Guidance(cfgs)
+        for si, cur in enumerate(guid.scenes):
+            for gi, (gname, _, _, fn) in enumerate(cur):
+                key = "%s_scene_%03d_%02d" % (gname, si, gi)
+                fn.draw = (torch.tensor(gold["%s/randint/%s" % (name, key)]),
+                           torch.tensor(gold["%s/rand/%s" % (name, key)]))
+        tr = traj0.clone().requires_grad_()
+        tot, per = guid.loss(tr, batch)
+        gt, = torch.autograd.grad(tot, tr)
+        assert torch.equal(tot.detach(), torch.tensor(gold[name + "/total"])), name
+        assert torch.equal(gt, torch.tensor(gold[name + "/grad"])), name
+        for k, v in per.items():
+            assert torch.equal(torch.nan_to_num(v), torch.nan_to_num(torch.tensor(gold["%s/per/%s" % (name, k)])))
+        assert float(gt.abs().max()) > 0

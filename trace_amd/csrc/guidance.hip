@@ -388,6 +388,87 @@ __global__ __launch_bounds__(256) void map_collision_kernel(
   }
 }
 
+// ---- SocialGroupLoss, guidance_loss.py:762-814 -------------------------------------------
+// Every member of a group keeps `social_dist` to ONE assigned neighbour per (sample, step): its
+// nearest group member, or (the caller's random draw, `pick`) another member.  The leader's position is
+// detached: it is pulled by nobody and pulls its followers.
+//   members[ag * G + s]  global agent index of the s-th member of ag's group (-1 = padding)
+//   pick[m * T + t]      >= 0: global index of the randomly assigned neighbour; -1: nearest
+// pass 1: nbr[m*T+t] (global agent index) and dist[m*T+t]; distances in the exact cdist form
+// (groups of <= 25 members keep ATen out of its matmul mode).
+template <int G>
+__global__ __launch_bounds__(256) void social_neighbor_kernel(
+    const float* __restrict__ ws, const int* __restrict__ members, const int* __restrict__ pick,
+    int* __restrict__ nbr, float* __restrict__ dist, const float* __restrict__ scale, int M,
+    int num_samp, int T) {
+  TRAJ_PROLOGUE();
+  if (lane >= T) return;
+  const int n = m - ag * num_samp;
+  const size_t i = (size_t)m * T + lane;
+  const float4 me = reinterpret_cast<const float4*>(ws)[i];
+  const int forced = pick ? pick[i] : -1;
+  float best = INFINITY;
+  int bj = -1;
+#pragma unroll 1
+  for (int s = 0; s < G; ++s) {
+    const int j = members[ag * G + s];
+    if (j < 0 || j == ag) continue;
+    const float4 ot = reinterpret_cast<const float4*>(ws)[((size_t)j * num_samp + n) * T + lane];
+    const float ex = me.x - ot.x, ey = me.y - ot.y;
+    const float d = sqrtf(ex * ex + ey * ey);
+    if (forced >= 0 ? j == forced : d < best) { best = d; bj = j; }
+  }
+  nbr[i] = bj;
+  dist[i] = best;
+}
+
+// pass 2: loss and owner-computes gradient: lane (ag, n, t) collects its own row's pull towards its
+// neighbour and the pull of every member whose assigned neighbour it is.
+template <int G>
+__global__ __launch_bounds__(256) void social_group_kernel(
+    const float* __restrict__ ws, float* __restrict__ grad, float* __restrict__ loss,
+    const float* __restrict__ wfa, const int* __restrict__ members, const int* __restrict__ is_leader,
+    const int* __restrict__ nbr, const float* __restrict__ dist, float social_dist,
+    const float* __restrict__ scale, int M, int num_samp, int T) {
+  TRAJ_PROLOGUE();
+  const int n = m - ag * num_samp;
+  const bool on = lane < T;
+  const int tl = on ? lane : T - 1;
+  const size_t i = (size_t)m * T + tl;
+  const float4 me = reinterpret_cast<const float4*>(ws)[i];
+  const float inv_t = 1.f / (float)T;
+  const float d = dist[i];
+  const int j = nbr[i];
+  const float diff = d - social_dist;
+  const float l = wave_sum(on && j >= 0 ? diff * diff : 0.f);
+  if (lane == 0) loss[m] = l * inv_t;
+  if (!grad || !on || is_leader[ag]) return;
+  float gwx = 0.f, gwy = 0.f;
+  if (j >= 0 && d > 0.f) {
+    const float4 ot = reinterpret_cast<const float4*>(ws)[((size_t)j * num_samp + n) * T + tl];
+    const float k = sc * (2.f * diff * inv_t) / d;
+    gwx += k * (me.x - ot.x);
+    gwy += k * (me.y - ot.y);
+  }
+#pragma unroll 1
+  for (int s = 0; s < G; ++s) {
+    const int o = members[ag * G + s];
+    if (o < 0 || o == ag) continue;
+    const size_t io = ((size_t)o * num_samp + n) * T + tl;
+    if (nbr[io] != ag) continue;
+    const float dd = dist[io];
+    if (!(dd > 0.f)) continue;
+    const float4 ot = reinterpret_cast<const float4*>(ws)[io];
+    const float k = scale[o] * (2.f * (dd - social_dist) * inv_t) / dd;
+    gwx += k * (me.x - ot.x);
+    gwy += k * (me.y - ot.y);
+  }
+  const float* A = wfa + (size_t)ag * 9;
+  float* gp = grad + ((size_t)m * T + lane) * 6;
+  gp[0] += A[0] * gwx + A[3] * gwy;
+  gp[1] += A[1] * gwx + A[4] * gwy;
+}
+
 // loss[m] = sum_t loss_mt[m*T + t] for active agents
 __global__ __launch_bounds__(256) void sum_over_time_kernel(const float* __restrict__ loss_mt,
                                                             float* __restrict__ loss,
@@ -503,4 +584,31 @@ extern "C" int trace_guide_map_collision(const float* traj, float* grad_traj, fl
   hipLaunchKernelGGL(sum_over_time_kernel, grid, block, 0, st, workspace, loss, scale, M, num_samp,
                      T);
   return launch_status("sum_over_time_kernel");
+}
+
+extern "C" int trace_guide_social_group(const float* traj, float* grad_traj, float* loss,
+                                        const float* world_from_agent, const int* members,
+                                        int group_width, const int* is_leader, const int* pick,
+                                        float social_dist, const float* scale, int n_agents,
+                                        int num_samp, int T, float* workspace, int* nbr_ws,
+                                        float* dist_ws, void* stream) {
+  const int M = n_agents * num_samp;
+  GUIDE_COMMON_CHECK("trace_guide_social_group");
+  TRACE_REQUIRE(world_from_agent && members && is_leader && workspace && nbr_ws && dist_ws,
+                "trace_guide_social_group: null table");
+  TRACE_REQUIRE(group_width == TRACE_SOCIAL_GROUP_WIDTH, "trace_guide_social_group: members table must be %d wide",
+                TRACE_SOCIAL_GROUP_WIDTH);
+  int n = M * T;
+  hipLaunchKernelGGL(world_pose_kernel, dim3((n + 255) / 256), dim3(256), 0, st, traj,
+                     world_from_agent, workspace, n, num_samp, T);
+  int rc = launch_status("world_pose_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(social_neighbor_kernel<TRACE_SOCIAL_GROUP_WIDTH>, grid, block, 0, st, workspace, members,
+                     pick, nbr_ws, dist_ws, scale, M, num_samp, T);
+  rc = launch_status("social_neighbor_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(social_group_kernel<TRACE_SOCIAL_GROUP_WIDTH>, grid, block, 0, st, workspace, grad_traj,
+                     loss, world_from_agent, members, is_leader, nbr_ws, dist_ws, social_dist, scale, M,
+                     num_samp, T);
+  return launch_status("social_group_kernel");
 }

@@ -16,9 +16,10 @@ from . import _cabi
 from ._cabi import ptr
 
 GUIDANCE_NAMES = ("target_speed", "agent_collision", "map_collision", "target_pos_at_time",
-                  "target_pos", "global_target_pos_at_time", "global_target_pos", "min_speed")
-_UNSUPPORTED = {"social_group": "draws torch.randint/rand inside the loss (guidance_loss.py:803-804)",
-                "amp_value": "needs an external value function (guidance_loss.py:816-849)"}
+                  "target_pos", "global_target_pos_at_time", "global_target_pos", "min_speed",
+                  "social_group")
+_UNSUPPORTED = {"amp_value": "needs an external value function (guidance_loss.py:816-849)"}
+SOCIAL_GROUP_WIDTH = 25          # TRACE_SOCIAL_GROUP_WIDTH of include/trace_hip.h
 SCENE_LEVEL = ("agent_collision", "social_group")
 
 
@@ -101,13 +102,18 @@ class DiffuserGuidance(object):
             if len(guidance_config_list[si]) > 0:
                 self.guide_configs[si] = [GuidanceConfig.from_dict(c) for c in guidance_config_list[si]]
         self.global_t = 0
+        # social_group only: injected neighbour draws {guide key name: (randint, rand)}, reused at every
+        # evaluation (parity tests); None = drawn on the device per evaluation
+        self.social_tape = None
 
     def update(self, global_t=None, **kwargs):
         if global_t is not None:
             self.global_t = global_t
 
-    def build_plan(self, data_batch, num_samp, horizon, device):
-        return GuidancePlan(self, data_batch, num_samp, horizon, device)
+    def build_plan(self, data_batch, num_samp, horizon, device, generator=None):
+        plan = GuidancePlan(self, data_batch, num_samp, horizon, device)
+        plan.social_tape, plan.generator = self.social_tape, generator
+        return plan
 
 
 def _transform_points(pts, mat):
@@ -192,6 +198,12 @@ class GuidancePlan:
                     self.drivable = batch["drivable_map"].to(device=device, dtype=torch.uint8).contiguous()
         M = B * self.N
         self.ws = torch.empty(M * self.T * 4, dtype=torch.float32, device=device)
+        self.generator = None            # torch.Generator for the social_group neighbour draws
+        self.social_tape = None          # {guide key name: (randint (T*N, G, 1), rand (T*N, G))}: injected draws
+        if any(ly["kind"] == "social_group" for ly in self.layers):
+            assert self.world_from_agent is not None, "social_group needs world_from_agent"
+            self.nbr_ws = torch.empty(M * self.T, dtype=torch.int32, device=device)
+            self.dist_ws = torch.empty(M * self.T, dtype=torch.float32, device=device)
         # selection tables (choose_action_from_guidance, guidance_loss.py:15-41)
         n_guides = torch.tensor([len(g) for g in guidance.guide_configs], dtype=torch.long)
         cover = torch.zeros(B, dtype=torch.long)
@@ -217,6 +229,9 @@ class GuidancePlan:
     def signature(self):
         """Hashable description of everything a captured launch sequence depends on besides the
         CONTENTS of the device tables: layer kinds / static keys / masks and table shapes."""
+        if any(ly["kind"] == "social_group" for ly in self.layers):
+            raise NotImplementedError("social_group draws random neighbours every evaluation: the step loop "
+                                      "cannot be replayed as a captured graph (use_graph=False)")
         layers = tuple((ly["kind"], ly["key"], tuple(ly["mask"].tolist()),
                         tuple(sorted((k, tuple(v.shape), str(v.dtype)) for k, v in ly["dev"].items())))
                        for ly in self.layers)
@@ -279,6 +294,26 @@ class GuidancePlan:
         if name == "map_collision":
             nlw = tuple(int(v) for v in p.get("num_points_lw", (10, 10)))
             return [_Item("map_collision", ("map_collision", nlw), mask, {"scale": sc})]
+        if name == "social_group":
+            coh = float(p.get("cohesion", 0.8))
+            assert 0.0 <= coh <= 1.0
+            if nm < 2:
+                raise ValueError("social_group needs at least two agents (the reference draws "
+                                 "torch.randint(0, B-1), guidance_loss.py:803)")
+            if nm > SOCIAL_GROUP_WIDTH:
+                raise NotImplementedError("social_group of %d agents: groups above %d members put torch.cdist "
+                                          "into its matmul mode (SURVEY.md appendix A); not built"
+                                          % (nm, SOCIAL_GROUP_WIDTH))
+            idx = torch.nonzero(mask, as_tuple=True)[0]                    # group order = batch order
+            members = torch.full((nm, SOCIAL_GROUP_WIDTH), -1, dtype=torch.int32)
+            members[:, :nm] = idx.to(torch.int32)[None]
+            # the reference compares the BATCH index with leader_idx (guidance_loss.py:775): kept
+            leader = (idx == int(p.get("leader_idx", 0))).to(torch.int32)
+            return [_Item("social_group", ("social_group", float(p.get("social_dist", 1.5))), mask,
+                          {"scale": sc, "members": members, "is_leader": leader,
+                           "cohesion": torch.full((nm,), coh, dtype=torch.float32),
+                           "gsize": torch.full((nm,), nm, dtype=torch.int64),
+                           "slot": torch.arange(nm, dtype=torch.int64)})]
         if name in ("global_target_pos", "global_target_pos_at_time"):
             tgt_w = torch.tensor(p["target_pos"], dtype=torch.float32).reshape(-1, 2)
             urg = torch.tensor(p["urgency"], dtype=torch.float32).reshape(-1)
@@ -365,11 +400,46 @@ class GuidancePlan:
                     ptr(traj), gp, ptr(loss), ptr(self.drivable), ptr(self.extent),
                     ptr(self.raster_from_agent), ptr(d["local"]), d["local"].shape[0], ptr(d["scale"]),
                     H, W, M, N, T, ptr(self.ws), stream)
+            elif kind == "social_group":
+                pick = self._social_pick(ly)
+                rc = L.trace_guide_social_group(
+                    ptr(traj), gp, ptr(loss), ptr(self.world_from_agent), ptr(d["members"]),
+                    SOCIAL_GROUP_WIDTH, ptr(d["is_leader"]), ptr(pick), ly["key"][1], ptr(d["scale"]),
+                    self.B, N, T, ptr(self.ws), ptr(self.nbr_ws), ptr(self.dist_ws), stream)
             else:
                 raise AssertionError(kind)
             _cabi.check(rc, "trace_guide_" + kind)
             out.append(loss)
         return out
+
+    def _social_pick(self, ly):
+        """(B, N, T) int32: the randomly assigned neighbour (global agent index) or -1 = nearest.
+        guidance_loss.py:797-808: with probability `cohesion` a member is paired with a uniformly drawn
+        OTHER member of its group instead of its nearest one.  The reference draws on the host every
+        evaluation; here the draw is on the device (``self.generator``), or injected (``social_tape``)."""
+        d, dev = ly["dev"], self.device
+        B, N, T = self.B, self.N, self.T
+        gs, slot = d["gsize"], d["slot"]
+        if self.social_tape is not None:
+            r = torch.zeros(B, N, T, dtype=torch.int64, device=dev)
+            u = torch.ones(B, N, T, dtype=torch.float32, device=dev)
+            for inst in self.instances:
+                if inst.name == "social_group" and inst.items[0].layer == self.layers.index(ly):
+                    ri, ui = self.social_tape[inst.key_name]
+                    G = int(inst.mask.sum())
+                    mk = inst.mask.to(dev)
+                    r[mk] = ri.to(dev).reshape(T, N, G).permute(2, 1, 0).to(torch.int64)
+                    u[mk] = ui.to(dev).reshape(T, N, G).permute(2, 1, 0).to(torch.float32)
+        else:
+            span = (gs - 1).clamp(min=1).to(torch.float32)[:, None, None]
+            r = (torch.rand(B, N, T, device=dev, generator=self.generator) * span).to(torch.int64)
+            r = torch.minimum(r, (gs - 2).clamp(min=0)[:, None, None])
+            u = torch.rand(B, N, T, device=dev, generator=self.generator)
+        rs = r + (r >= slot[:, None, None]).to(torch.int64)             # skip self in the choice list
+        cand = torch.gather(d["members"].to(torch.int64), 1,
+                            rs.reshape(B, N * T).clamp(max=SOCIAL_GROUP_WIDTH - 1)).reshape(B, N, T)
+        take = u < d["cohesion"][:, None, None]
+        return torch.where(take, cand, torch.full_like(cand, -1)).to(torch.int32).contiguous()
 
     def instance_loss(self, key_name, layer_losses):
         for inst in self.instances:

@@ -196,7 +196,7 @@ class TraceSampler:
                     "trace_unet_cond_table")
 
         guidance = self.current_guidance
-        plan = guidance.build_plan(data_batch, N, T, dev) if guidance is not None else None
+        plan = guidance.build_plan(data_batch, N, T, dev, generator) if guidance is not None else None
         guided = plan is not None and apply_guidance
         save = 1 if (guided and guide_clean) else 0
         ws_bytes = L.trace_unet_workspace_bytes(self._unet, R, save)

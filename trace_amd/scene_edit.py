@@ -180,7 +180,7 @@ def heuristic_map_collision(sim_scene, dt, num_points_lw):
 def heuristic_social_group(sim_scene, dt, group_dist_thresh, social_dist, cohesion):
     """Groups = connected components of the graph "closer than ``group_dist_thresh`` and not walking in
     opposing directions" (:181-229); one ``social_group`` guide per group of two or more, with a
-    random leader.  (The ``social_group`` objective itself is not built yet: DESIGN.md section 8.)"""
+    random leader."""
     from scipy.sparse.csgraph import connected_components
     cur = get_agents_curr(sim_scene)
     pos, vel = cur[:, :2], cur[:, 2:4]
