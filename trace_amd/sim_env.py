@@ -413,14 +413,20 @@ class CollisionRate:
 
     def add_step(self, obs, scene_index):
         p, sid, r = obs["centroid"], obs["scene_index"], obs["extent"][:, 1] / 2.0
-        hit = torch.zeros(p.shape[0], dtype=torch.bool, device=p.device)
-        _, inv = torch.unique_consecutive(sid, return_inverse=True)
+        B, dev = p.shape[0], p.device
+        _, inv, counts = torch.unique_consecutive(sid, return_inverse=True, return_counts=True)
         self._inv = inv
-        for s in range(int(inv.max()) + 1) if p.shape[0] else []:
-            idx = torch.nonzero(inv == s, as_tuple=True)[0]
-            d = torch.cdist(p[idx], p[idx]) - (r[idx][:, None] + r[idx][None, :])
-            d.fill_diagonal_(float("inf"))
-            hit[idx] = (d < 0).any(1)
+        # padded per-scene layout (S, Amax): one batched all-pairs test instead of a loop over scenes
+        S, A = counts.shape[0], int(counts.max())
+        start = torch.cumsum(counts, 0) - counts
+        slot = torch.arange(B, device=dev) - start[inv]
+        pp = torch.full((S, A, 2), float("inf"), device=dev)
+        rr = torch.zeros(S, A, device=dev)
+        pp[inv, slot] = p
+        rr[inv, slot] = r
+        d = torch.linalg.norm(pp[:, :, None] - pp[:, None, :], dim=-1) - (rr[:, :, None] + rr[:, None, :])
+        d = torch.where(torch.eye(A, dtype=torch.bool, device=dev)[None], torch.full_like(d, float("inf")), d)
+        hit = (torch.nan_to_num(d, nan=float("inf")) < 0).any(-1)[inv, slot]
         self._hit = hit if self._hit is None else (self._hit | hit)
 
     def get_episode_metrics(self):
