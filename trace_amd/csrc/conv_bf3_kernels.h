@@ -157,16 +157,20 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
                           : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, jj * L_IN * 4, 0));
     }
   };
-  auto stage_write = [&]() {
+#ifndef TRACE_BF3_SPLIT_IN_K
+#define TRACE_BF3_SPLIT_IN_K 0    // split the next chunk into bf16 planes between the MFMAs of the current one
+#endif
+  u32x4v sph[NUT], spm[NUT], spl[NUT];
+  auto split_unit = [&](int j) { split8_bf16(stg[j], sph[j], spm[j], spl[j]); };
+  auto stage_write = [&](const bool presplit) {
 #pragma unroll
     for (int j = 0; j < NUT; ++j) {
       if ((NU % 256 == 0) || (tid + 256 * j < NU)) {
-        u32x4v h, m, l;
-        split8_bf16(stg[j], h, m, l);
+        if (!presplit) split_unit(j);
         char* p = ldsb + wofs[j];
-        *reinterpret_cast<u32x4v*>(p) = h;
-        *reinterpret_cast<u32x4v*>(p + PLANE) = m;
-        *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = l;
+        *reinterpret_cast<u32x4v*>(p) = sph[j];
+        *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
+        *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = spl[j];
       }
     }
   };
@@ -270,6 +274,12 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
 #pragma unroll
         for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
       }
+      if constexpr (TRACE_BF3_SPLIT_IN_K) {
+        // the loads issued at n == 1 have landed by the last tiles of the chunk: split one staging unit per
+        // tile there, in the shadow of the MFMAs, so that the chunk switch is only barrier - write - barrier
+        constexpr int FIRST = NT - NUT > 2 ? NT - NUT : 2;
+        if (next >= 0 && n >= FIRST && n - FIRST < NUT) split_unit(n - FIRST);
+      }
       const int s = n % NST, rt = n % NRT;
       f32x4 c = acc[rt];
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][2], b[0], c, 0, 0, 0);
@@ -285,7 +295,7 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
   TRACE_STAMP(14);
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();            // previous chunk fully consumed (and zero fill done)
-    stage_write();
+    stage_write(TRACE_BF3_SPLIT_IN_K && ch > 0);
     if (ch == 0) TRACE_STAMP(15);
     __syncthreads();
     if (ch == 0) TRACE_STAMP(1);
