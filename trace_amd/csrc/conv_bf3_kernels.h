@@ -160,13 +160,14 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
 #ifndef TRACE_BF3_SPLIT_IN_K
 #define TRACE_BF3_SPLIT_IN_K 0    // split the next chunk into bf16 planes between the MFMAs of the current one
 #endif
+  constexpr bool SPLITK = TRACE_BF3_SPLIT_IN_K && TAPS > 1;     // the 1x1 kernels have no MFMA shadow to hide it in
   u32x4v sph[NUT], spm[NUT], spl[NUT];
   auto split_unit = [&](int j) { split8_bf16(stg[j], sph[j], spm[j], spl[j]); };
-  auto stage_write = [&](const bool presplit) {
+  // the bf16 planes of the staged chunk go to LDS from sph / spm / spl
+  auto stage_write = [&]() {
 #pragma unroll
     for (int j = 0; j < NUT; ++j) {
       if ((NU % 256 == 0) || (tid + 256 * j < NU)) {
-        if (!presplit) split_unit(j);
         char* p = ldsb + wofs[j];
         *reinterpret_cast<u32x4v*>(p) = sph[j];
         *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
@@ -270,15 +271,15 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
         }
       }
       if (n + DIST < NT) load_a(n + DIST, (n + DIST) % NST);
-      if (n == 1 && next >= 0) {
+      if (n == 1 && (SPLITK || next >= 0)) {
 #pragma unroll
         for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
       }
-      if constexpr (TRACE_BF3_SPLIT_IN_K) {
+      if constexpr (SPLITK) {
         // the loads issued at n == 1 have landed by the last tiles of the chunk: split one staging unit per
         // tile there, in the shadow of the MFMAs, so that the chunk switch is only barrier - write - barrier
         constexpr int FIRST = NT - NUT > 2 ? NT - NUT : 2;
-        if (next >= 0 && n >= FIRST && n - FIRST < NUT) split_unit(n - FIRST);
+        if (n >= FIRST && n - FIRST < NUT) split_unit(n - FIRST);
       }
       const int s = n % NST, rt = n % NRT;
       f32x4 c = acc[rt];
@@ -294,12 +295,17 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
 
   TRACE_STAMP(14);
   for (int ch = 0; ch < nch; ++ch) {
+    if (!SPLITK || ch == 0) {
+#pragma unroll
+      for (int j = 0; j < NUT; ++j) split_unit(j);
+    }
     __syncthreads();            // previous chunk fully consumed (and zero fill done)
-    stage_write(TRACE_BF3_SPLIT_IN_K && ch > 0);
+    stage_write();
     if (ch == 0) TRACE_STAMP(15);
     __syncthreads();
     if (ch == 0) TRACE_STAMP(1);
-    const int next = ch + 1 < nch ? ch + 1 : -1;
+    // with the in-K split the body is branch-free: the last chunk re-stages itself (never written)
+    const int next = ch + 1 < nch ? ch + 1 : (SPLITK ? ch : -1);
     if (ch < nch1)
       chunk_mma(std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{}, next);
     else
