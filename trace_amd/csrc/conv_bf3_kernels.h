@@ -295,11 +295,11 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
 
   TRACE_STAMP(14);
   for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();            // previous chunk fully consumed (and zero fill done)
     if (!SPLITK || ch == 0) {
 #pragma unroll
       for (int j = 0; j < NUT; ++j) split_unit(j);
     }
-    __syncthreads();            // previous chunk fully consumed (and zero fill done)
     stage_write();
     if (ch == 0) TRACE_STAMP(15);
     __syncthreads();
