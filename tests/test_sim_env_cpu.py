@@ -250,3 +250,25 @@ def test_reference_eval_jsons_load_unchanged():
                 assert h["name"] == r["name"] and h["weight"] == r["weight"]
             n += 1
     assert n >= 5
+
+
+def test_reference_import_paths_resolve_through_the_shim():
+    """A driver written against the reference's import paths (scripts/scene_editor.py:12-18,48) finds
+    the MI355X implementation when trace_amd/compat is on the path (option B)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib\n"
+            "from tbsim.configs.scene_edit_config import SceneEditingConfig\n"
+            "from tbsim.utils.scene_edit_utils import guided_rollout, compute_heuristic_guidance, merge_guidance_configs\n"
+            "from tbsim.policies.wrappers import RolloutWrapper, PolicyWrapper\n"
+            "from tbsim.policies.common import Action, RolloutAction\n"
+            "from tbsim.envs.env_trajdata import EnvUnifiedSimulation\n"
+            "cfg = SceneEditingConfig()\n"
+            "cls = getattr(importlib.import_module('tbsim.evaluation.policy_composers'), cfg.eval_class)\n"
+            "import trace_amd.policy, trace_amd.scene_edit\n"
+            "assert cls is trace_amd.policy.Diffuser and guided_rollout is trace_amd.scene_edit.guided_rollout\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.path.join(root, "trace_amd", "compat") + os.pathsep + root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
