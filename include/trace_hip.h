@@ -252,6 +252,19 @@ int trace_guide_social_group(const float* traj, float* grad_traj, float* loss,
                              const float* scale, int n_agents, int num_samp, int T,
                              float* workspace, int* nbr_ws, float* dist_ws, void* stream);
 
+/* Agent-centric drivable raster of the closed-loop environment (the map
+ * crop + rotate that trajdata's collation does on the host for the reference,
+ * trajdata/src/trajdata/data_structures/collation.py:17-255, and the drivable layer of
+ * tbsim/utils/trajdata_utils.py:85-132), for synthetic scenes whose obstacles are axis-aligned boxes.
+ *   pose (n_agents, 3) world x, y, yaw;  scene_of_agent (n_agents) int32 row into boxes;
+ *   boxes (n_scenes, n_boxes, 4) centre x, y, half sizes;  raster_from_agent_host: 9 floats in HOST
+ *   memory (shared by all agents, trajdata_utils.py:196-200; must be scale + offset)
+ *   image (n_agents, channels, H, W) float or NULL: channel 0 = drivable, 1 = obstacle, others 0;
+ *   drivable (n_agents, H, W) uint8 or NULL.  W % 4 == 0, n_agents <= 65535. */
+int trace_env_rasterize(const float* pose, const int* scene_of_agent, const float* boxes, int n_boxes,
+                        const float* raster_from_agent_host, float* image, int channels,
+                        uint8_t* drivable, int n_agents, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -373,3 +373,67 @@ extern "C" int trace_posterior_step(const float* x0, const float* grad, const fl
                      x0, grad, x, noise, curr_states, x_next, a_out, M, num_samp, T, clean, *c, *p);
   return launch_status("posterior_step_kernel");
 }
+
+// ---- environment side: agent-centric drivable raster --------------------
+// One thread = 4 consecutive pixels of one agent's H x W raster: pixel centre -> agent frame
+// (inverse of raster_from_agent, trajdata_utils.py:196-200) -> world (the agent's pose) -> inside test
+// against the axis-aligned obstacle boxes of the agent's scene.  Pure HBM write stream:
+// (4 C + 1) bytes per pixel out, a few hundred bytes per agent in.
+namespace trace {
+__global__ __launch_bounds__(256) void env_rasterize_kernel(
+    const float* __restrict__ pose, const int* __restrict__ scene_of_agent,
+    const float* __restrict__ boxes, int n_boxes, float r00, float r02, float r11, float r12,
+    float* __restrict__ image, int channels, uint8_t* __restrict__ drivable, int H, int W) {
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;        // quad of pixels
+  const int npix = H * W;
+  if (q * 4 >= npix) return;
+  const int py = (q * 4) / W, px0 = (q * 4) - py * W;
+  const float x0 = pose[b * 3], y0 = pose[b * 3 + 1], yaw = pose[b * 3 + 2];
+  const float c = cosf(yaw), s = sinf(yaw);
+  const float* bx = boxes + (size_t)scene_of_agent[b] * n_boxes * 4;
+  const float ay = ((float)py - r12) / r11;
+  float drv[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float ax = ((float)(px0 + e) - r02) / r00;
+    const float wx = (c * ax - s * ay) + x0;
+    const float wy = (s * ax + c * ay) + y0;
+    bool free_cell = true;
+    for (int k = 0; k < n_boxes; ++k)
+      free_cell = free_cell && !(fabsf(wx - bx[4 * k]) < bx[4 * k + 2] && fabsf(wy - bx[4 * k + 1]) < bx[4 * k + 3]);
+    drv[e] = free_cell ? 1.f : 0.f;
+  }
+  if (drivable) {
+    uchar4 d;
+    d.x = drv[0] != 0.f; d.y = drv[1] != 0.f; d.z = drv[2] != 0.f; d.w = drv[3] != 0.f;
+    reinterpret_cast<uchar4*>(drivable + (size_t)b * npix)[q] = d;
+  }
+  if (image) {
+    float4* img = reinterpret_cast<float4*>(image + (size_t)b * channels * npix);
+    img[q] = float4{drv[0], drv[1], drv[2], drv[3]};
+    if (channels > 1) img[npix / 4 + q] = float4{1.f - drv[0], 1.f - drv[1], 1.f - drv[2], 1.f - drv[3]};
+    for (int ch = 2; ch < channels; ++ch) img[(size_t)ch * (npix / 4) + q] = float4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+}  // namespace trace
+
+extern "C" int trace_env_rasterize(const float* pose, const int* scene_of_agent, const float* boxes,
+                                   int n_boxes, const float* raster_from_agent_host, float* image,
+                                   int channels, uint8_t* drivable, int n_agents, int H, int W,
+                                   void* stream) {
+  TRACE_REQUIRE(pose && scene_of_agent && raster_from_agent_host && (image || drivable) && (boxes || n_boxes == 0),
+                "trace_env_rasterize: null argument");
+  TRACE_REQUIRE(n_agents >= 0 && H > 0 && W > 0 && W % 4 == 0 && n_boxes >= 0 && channels >= 1 && n_agents <= 65535,
+                "trace_env_rasterize: bad shape agents=%d H=%d W=%d channels=%d (W must be a multiple of 4)",
+                n_agents, H, W, channels);
+  if (n_agents == 0) return TRACE_OK;
+  const float* r = raster_from_agent_host;
+  TRACE_REQUIRE(r[0] != 0.f && r[4] != 0.f && r[1] == 0.f && r[3] == 0.f,
+                "trace_env_rasterize: raster_from_agent must be an axis-aligned scale + offset");
+  const int quads = H * W / 4;
+  dim3 grid((quads + 255) / 256, n_agents), block(256);
+  hipLaunchKernelGGL(trace::env_rasterize_kernel, grid, block, 0, (hipStream_t)stream, pose, scene_of_agent, boxes,
+                     n_boxes, r[0], r[2], r[4], r[5], image, channels, drivable, H, W);
+  return trace::launch_status("env_rasterize_kernel");
+}

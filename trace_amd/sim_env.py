@@ -219,6 +219,36 @@ class SceneBatchEnv:
 
     # ---- observation builder ------------------------------------------------------------------ #
     def _rasterize(self, pose):
+        """image (B, C, H, W) float and drivable (B, H, W) bool of every agent's frame.  On a GPU this is
+        the HIP kernel ``trace_env_rasterize`` (csrc/steps.hip; raises if the library is missing);
+        ``_rasterize_torch`` is the host-logic restatement the CPU tests run."""
+        C, H, W = self.cfg.image_shape
+        B = pose.shape[0]
+        if self.device.type != "cuda":
+            drv = self._rasterize_torch(pose)
+            img = torch.zeros((B, C, H, W), dtype=torch.float32, device=self.device)
+            img[:, 0] = drv
+            if C > 1:
+                img[:, 1] = ~drv
+            return img, drv
+        import ctypes
+        from . import _cabi
+        L = _cabi.lib()
+        img = torch.empty((B, C, H, W), dtype=torch.float32, device=self.device)
+        drv = torch.empty((B, H, W), dtype=torch.uint8, device=self.device)
+        pose_c = pose.contiguous()
+        soa = self._scene_index.to(torch.int32).contiguous()
+        boxes = self._boxes.contiguous()
+        rfa = (ctypes.c_float * 9)(*[float(v) for v in self._rfa.flatten().tolist()])
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        for lo in range(0, B, 65535):
+            hi = min(B, lo + 65535)
+            _cabi.check(L.trace_env_rasterize(pose_c[lo:hi].data_ptr(), soa[lo:hi].data_ptr(), boxes.data_ptr(),
+                                              boxes.shape[1], ctypes.byref(rfa), img[lo:hi].data_ptr(), C,
+                                              drv[lo:hi].data_ptr(), hi - lo, H, W, st), "trace_env_rasterize")
+        return img, drv.view(torch.bool)
+
+    def _rasterize_torch(self, pose):
         """(B, H, W) bool drivable layer in each agent's frame: pixel centres -> agent -> world, then
         inside tests against the scene's boxes.  Chunked so the temporaries stay below ~1 GB."""
         C, H, W = self.cfg.image_shape
@@ -316,13 +346,7 @@ class SceneBatchEnv:
             "curr_agent_state": pose.clone(),
         }
         if self.with_image:
-            C = self.cfg.image_shape[0]
-            drv = self._rasterize(pose)
-            img = torch.zeros((B, C) + tuple(drv.shape[1:]), dtype=torch.float32, device=dev)
-            img[:, 0] = drv
-            if C > 1:
-                img[:, 1] = ~drv
-            obs["image"], obs["drivable_map"] = img, drv
+            obs["image"], obs["drivable_map"] = self._rasterize(pose)
         self._cached_observation = dict(agents=obs)
         return self._cached_observation
 
