@@ -49,11 +49,17 @@ def run_scene_editor(eval_cfg, save_cfg, env_args, composer_args, use_gt=False, 
     policy, exp_config = composer_class(eval_cfg, device, **composer_args).get_policy()
     exp_config = Dict(exp_config)
     policy_model = policy.model
+    algo_config = policy_model.algo_config
+    if use_gt:
+        # the recorded future instead of the model (scene_editor.py:53-58)
+        from trace_amd.policy import GTNaNPolicy
+        policy, policy_model = GTNaNPolicy(device=device), None
+        print("WARNING: Using GT data as the policy instead of the provided model!!")
     rollout_policy = RolloutWrapper(agents_policy=policy)
 
     metrics = {"all_collision_rate": CollisionRate(), "all_off_road_rate": OffRoadRate()} \
         if eval_cfg.metrics.compute_analytical_metrics else {}
-    env = SceneBatchEnv(policy_model.algo_config, device=device, seed=eval_cfg.seed,
+    env = SceneBatchEnv(algo_config, device=device, seed=eval_cfg.seed,
                         num_scenes=eval_cfg.num_scenes_per_batch,
                         num_simulation_steps=eval_cfg.num_simulation_steps, metrics=metrics, **env_args)
 
@@ -130,7 +136,6 @@ def main(argv=None):
     p.add_argument("--num_scenes_to_evaluate", type=int, default=None)
     args = p.parse_args(argv)
     assert not (args.render or args.render_img), "rendering is not built (SURVEY.md section 2: out of scope)"
-    assert not args.ground_truth, "the GT replay policy is not built (SURVEY.md section 2: out of scope)"
 
     cfg = SceneEditingConfig()
     if args.config_file is not None:
@@ -144,7 +149,8 @@ def main(argv=None):
                                editing_source=args.editing_source)
     env_args = dict(agents_per_scene=[args.synthetic_agents] * args.synthetic_scenes, dense=args.synthetic_dense)
     composer_args = dict(allow_random_init=args.allow_random_init, seed=cfg.seed, random_map_encoder=True)
-    return run_scene_editor(cfg, save_cfg=True, env_args=env_args, composer_args=composer_args)
+    return run_scene_editor(cfg, save_cfg=True, env_args=env_args, composer_args=composer_args,
+                            use_gt=args.ground_truth)
 
 
 if __name__ == "__main__":

@@ -56,6 +56,9 @@ def test_scene_editor_cli_closed_loop(tmp_path):
     assert on_disk["ade"] == stats["ade"].tolist()
     # agents moved: a 3 s rollout of 1-2 m/s pedestrians under random weights stays within tens of metres
     assert 0.0 < float(stats["fde"].max()) < 60.0
+    # --ground_truth replays the recorded future through the same loop (scene_editor.py:53-58)
+    gt = se.main(args + ["--ground_truth", "--prefix", "gt_"])
+    assert float(gt["ade"].max()) < 1e-3 and float(gt["fde"].max()) < 1e-3
 
 
 def test_closed_loop_replan_matches_oracle_on_env_observation():

@@ -272,3 +272,20 @@ def test_reference_import_paths_resolve_through_the_shim():
     env = dict(os.environ, PYTHONPATH=os.path.join(root, "trace_amd", "compat") + os.pathsep + root)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_gt_replay_policy_reproduces_the_recorded_future():
+    """GTNaNPolicy (hardcoded.py:8-29) on the env's target_positions: zero ADE / FDE in closed loop, and
+    the targets are expressed in the CURRENT agent frame after a step."""
+    from trace_amd.policy import GTNaNPolicy
+    env = make_env()
+    policy = RolloutWrapper(agents_policy=GTNaNPolicy("cpu"))
+    stats, _ = se.guided_rollout(env, policy, None, n_step_action=4, guidance_config=None,
+                                 scene_indices=[0, 1, 2], horizon=20, use_gt=True)
+    assert float(stats["ade"].max()) < 1e-4 and float(stats["fde"].max()) < 1e-4
+    env.reset(scene_indices=[1])
+    obs = env.get_observation()["agents"]
+    assert obs["target_positions"].shape == (3, 52, 2) and bool(obs["target_availabilities"].all())
+    speed = obs["curr_speed"]
+    np.testing.assert_allclose(obs["target_positions"][:, 9, 0].numpy(), (speed * 1.0).numpy(), atol=1e-5)
+    np.testing.assert_allclose(obs["target_positions"][:, :, 1].numpy(), 0.0, atol=1e-5)

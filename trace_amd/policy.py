@@ -155,6 +155,25 @@ def choose_action_from_gt(preds, obs_dict):
     return torch.where(ok, best, idx)
 
 
+class GTNaNPolicy(object):
+    """Replays the recorded future of the observation as the plan; unavailable frames are NaN
+    (/root/reference/tbsim/policies/hardcoded.py:8-29; ``scripts/scene_editor.py --ground_truth``)."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+
+    def eval(self):
+        pass
+
+    def get_action(self, obs, **kwargs):
+        invalid = ~torch.as_tensor(obs["target_availabilities"]).bool().to(self.device)
+        pos = torch.as_tensor(obs["target_positions"]).to(self.device, torch.float32).clone()
+        yaw = torch.as_tensor(obs["target_yaws"]).to(self.device, torch.float32).clone()
+        pos[invalid] = float("nan")
+        yaw[invalid] = float("nan")
+        return Action(positions=pos, yaws=yaw), {}
+
+
 class DiffuserTrafficModel(object):
     """Algo-level object with the reference's inference interface (algos.py:19-326).  Holds one
     ``TraceSampler`` (the EMA copy is what inference uses, algos.py:268-271)."""

@@ -345,6 +345,17 @@ class SceneBatchEnv:
             "centroid": pose[:, :2].clone(), "yaw": pose[:, 2].clone(),
             "curr_agent_state": pose.clone(),
         }
+        # recorded future ("ground truth": the constant-velocity continuation of the initial state) in
+        # the CURRENT agent frame: target_positions / target_yaws / target_availabilities of the parsed
+        # batch (trajdata_utils.py:241-243), consumed by guide_with_gt and the GT replay policy
+        T = self.cfg.horizon
+        kk = (self._frame_index + 1 + torch.arange(T, device=dev, dtype=torch.float32)) * self.cfg.step_time
+        hv0 = torch.stack([torch.cos(self._init_pose[:, 2]), torch.sin(self._init_pose[:, 2])], -1)
+        fut_w = self._init_pose[:, None, :2] + hv0[:, None] * (self._init_speed[:, None, None] * kk[None, :, None])
+        fut = torch.cat([fut_w, self._init_pose[:, None, 2:3].expand(B, T, 1)], -1)
+        fp, fy = to_local(fut, c[:, None], s[:, None], pose)
+        obs["target_positions"], obs["target_yaws"] = fp, fy
+        obs["target_availabilities"] = torch.ones(B, T, dtype=torch.bool, device=dev)
         if self.with_image:
             obs["image"], obs["drivable_map"] = self._rasterize(pose)
         self._cached_observation = dict(agents=obs)
