@@ -293,6 +293,16 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
     }
   };
 
+#ifndef TRACE_BF3_PRIO
+#define TRACE_BF3_PRIO 0          // 1: K-loop waves at issue priority 3; 2: 3 / 1 by bit 8 of the workgroup id
+#endif
+  if constexpr (TRACE_BF3_PRIO == 1) {
+    __builtin_amdgcn_s_setprio(3);
+  } else if constexpr (TRACE_BF3_PRIO == 2) {
+    // workgroups i and i + 256 share a CU (scripts/probe/wg_map.hip): unequal priorities take the two
+    // out of lock-step, so that one's K loop runs beside the other's epilogue / prologue
+    if ((blockIdx.x >> 8) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+  }
   TRACE_STAMP(14);
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();            // previous chunk fully consumed (and zero fill done)
@@ -316,6 +326,7 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
     else if (ch == nch - 1) TRACE_STAMP(5);
   }
 
+  if constexpr (TRACE_BF3_PRIO != 0) __builtin_amdgcn_s_setprio(0);
   conv_epilogue<L_OUT, TB, 1>(a, acc, lds, traj0, co0);
 }
 
