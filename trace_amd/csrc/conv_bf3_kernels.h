@@ -82,7 +82,8 @@ struct Bf3Geom {
   static constexpr int NPOS = TB * L_IN;                   // data positions per chunk
   static constexpr int NU = NPOS * (CH / 8);               // staging units (position, channel octet)
   static constexpr int NUT = (NU + 255) / 256;
-  static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float);      // the output tile (conv_epilogue)
+  // the output tile (conv_epilogue) + the 32-channel-group exchange area of conv_epilogue_fwd_rows
+  static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float) + 2 * 4 * TB * sizeof(float);
   static constexpr size_t LDS_BYTES = (size_t)3 * PLANE > EPI_BYTES ? (size_t)3 * PLANE : EPI_BYTES;
   static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0 && PPT * NRT == L_OUT && PPT * TB == 16, "bad tile");
   static_assert(3 * PLANE < 65536, "LDS immediates must fit 16 bits");
@@ -327,7 +328,13 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
   }
 
   if constexpr (TRACE_BF3_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-  conv_epilogue<L_OUT, TB, 1>(a, acc, lds, traj0, co0);
+#ifndef TRACE_BF3_EPI_REGS
+#define TRACE_BF3_EPI_REGS 0      // forward GroupNorm / Mish on the accumulators (conv_epilogue_fwd_rows)
+#endif
+  if (TRACE_BF3_EPI_REGS && !a.gnb)
+    conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0);
+  else
+    conv_epilogue<L_OUT, TB, 1>(a, acc, lds, traj0, co0);
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>

@@ -512,6 +512,197 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
   TRACE_STAMP(11);
 }
 
+// ---- forward epilogue of the trajectory-major tiles (conv_bf3_kernel), statistics in registers ----
+// In the trajectory-major accumulator layout every lane holds COMPLETE (trajectory, channel) rows:
+// channel = 16 wave + (lane & 15); with PPT = L_OUT / 13 positions per row tile a lane owns
+// NPR = 4 / PPT trajectories (q NPR + j, q = lane >> 4), row j = registers j PPT .. j PPT + PPT - 1 of all 13
+// accumulator tiles.  GroupNorm moments, normalisation, Mish and the condition add therefore run on
+// the accumulators before they leave the registers: the tile goes through LDS once, finished
+// (twice when the raw conv output is saved for the backward).  Groups of 8 / 16 channels reduce inside
+// the wave's 16-lane rows (DPP); groups of 32 channels span two waves and exchange their 16-channel
+// partial sums through 512 B of LDS behind the tile.
+template <int L_OUT, int TB>
+__device__ __forceinline__ void conv_epilogue_fwd_rows(const ConvArgs& a, f32x4 (&acc)[TB * L_OUT / 16],
+                                                       float* lds, const int traj0, const int co0) {
+  constexpr int R = TB * L_OUT, NRT = R / 16, PPT = L_OUT / NRT, NPR = 4 / PPT;
+  constexpr int TILE = 64 * L_OUT;
+  constexpr int NQ = R * 64 / 4 / 256;
+  static_assert(PPT * NRT == L_OUT && PPT * TB == 16 && (PPT == 1 || PPT == 2 || PPT == 4), "bad tile");
+  typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int col = lane & 15, q = lane >> 4;
+  const int co_l = wave * 16 + col, co = co0 + co_l;
+  const bool has_tab = a.gn || a.pc;
+  auto flat_off = [&](int k, int tstride, int coff) -> unsigned {
+    const int f = (tid + 256 * k) * 4;
+    const int tr = f / TILE;
+    const int rem = f - tr * TILE;
+    const int tg = traj0 + tr;
+    return tg < a.rows ? ((unsigned)tg * (unsigned)tstride + (unsigned)((coff + co0) * L_OUT + rem)) * 4u
+                       : 0xffffffffu;
+  };
+  f32x4 rv[NQ];
+  if (a.res) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res), 0, (unsigned)((size_t)a.rows * a.res_tstride * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+      rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rr, flat_off(k, a.res_tstride, a.res_coff), 0, 0));
+  } else {
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (a.res2) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.res2), 0, (unsigned)((size_t)a.rows * a.res2_tstride * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k)
+      rv[k] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                             rr, flat_off(k, a.res2_tstride, a.res2_coff), 0, 0));
+  }
+
+  {  // conv bias
+    const float bv = a.bias ? a.bias[co] : 0.f;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) { acc[rt][0] += bv; acc[rt][1] += bv; acc[rt][2] += bv; acc[rt][3] += bv; }
+  }
+  // accumulators -> tile laid out like the global tensor ([trajectory][channel][position])
+  auto write_tile = [&]() {
+    float* tcol = lds + co_l * L_OUT;
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt) {
+      const f32x4 v = acc[rt];
+      if constexpr (PPT == 4) {
+        *reinterpret_cast<f32x4*>(tcol + q * TILE + 4 * rt) = v;
+      } else if constexpr (PPT == 2) {
+        *reinterpret_cast<float2*>(tcol + (2 * q) * TILE + 2 * rt) = float2{v[0], v[1]};
+        *reinterpret_cast<float2*>(tcol + (2 * q + 1) * TILE + 2 * rt) = float2{v[2], v[3]};
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) tcol[(4 * q + reg) * TILE + rt] = v[reg];
+      }
+    }
+  };
+  if (a.ysave) {
+    __syncthreads();                       // every wave is out of the K loop's LDS image
+    write_tile();
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        a.ysave, 0, (unsigned)((size_t)a.rows * a.cout * L_OUT * sizeof(float)), 0x00020000);
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const f32x4 y = *reinterpret_cast<const f32x4*>(lds + (tid + 256 * k) * 4);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ry, flat_off(k, a.cout * L_OUT, 0), 0, 0);
+    }
+  }
+  TRACE_STAMP(10);
+
+  if (has_tab) {
+    const float gam = a.gn ? a.gamma[co] : 1.f;
+    const float bet = a.gn ? a.beta[co] : 0.f;
+    const float ptv = a.pc ? a.pt[co] : 0.f;
+    const int cg = a.gn ? a.cg : 1;
+    float add[NPR], scale[NPR], shift[NPR];
+#pragma unroll
+    for (int j = 0; j < NPR; ++j) {
+      const int tg = min(traj0 + q * NPR + j, a.rows - 1);
+      add[j] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
+      scale[j] = 1.f;
+      shift[j] = 0.f;
+    }
+    if (a.gn) {
+      float rmean[NPR], m2[NPR], gs[NPR], gv[NPR];
+#pragma unroll
+      for (int j = 0; j < NPR; ++j) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+          for (int e = 0; e < PPT; ++e) sacc += acc[rt][j * PPT + e];
+        const float rm = sacc * (1.f / (float)L_OUT);
+        float qq = 0.f;
+#pragma unroll
+        for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+          for (int e = 0; e < PPT; ++e) {
+            const float d = acc[rt][j * PPT + e] - rm;
+            qq = fmaf(d, d, qq);
+          }
+        rmean[j] = rm;
+        m2[j] = qq;
+        gs[j] = rm;
+      }
+      TRACE_STAMP(6);
+      // two waves' 16-channel partial sums -> the 32-channel group (both waves add in the same order)
+      float* xch = lds + R * 64;            // [round][wave][TB]
+      auto pair_sum = [&](float (&v)[NPR], int round) {
+        if (col == 0) {
+#pragma unroll
+          for (int j = 0; j < NPR; ++j) xch[(round * 4 + wave) * TB + q * NPR + j] = v[j];
+        }
+        __syncthreads();
+        const int w0 = wave & ~1;
+#pragma unroll
+        for (int j = 0; j < NPR; ++j)
+          v[j] = xch[(round * 4 + w0) * TB + q * NPR + j] + xch[(round * 4 + w0 + 1) * TB + q * NPR + j];
+      };
+      group_sum<NPR>(gs, cg < 16 ? cg : 16);
+      if (cg > 16) pair_sum(gs, 0);
+#pragma unroll
+      for (int j = 0; j < NPR; ++j) {
+        gs[j] = gs[j] / (float)cg;                       // group mean
+        const float dm = rmean[j] - gs[j];
+        gv[j] = fmaf(dm * dm, (float)L_OUT, m2[j]);
+      }
+      group_sum<NPR>(gv, cg < 16 ? cg : 16);
+      if (cg > 16) pair_sum(gv, 1);
+      TRACE_STAMP(7);
+#pragma unroll
+      for (int j = 0; j < NPR; ++j) {
+        const int tr = q * NPR + j;
+        const float mean = gs[j];
+        const float var = gv[j] / (float)(cg * L_OUT);
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        scale[j] = rstd * gam;
+        shift[j] = bet - mean * scale[j];
+        if (a.stats && (co & (cg - 1)) == 0 && traj0 + tr < a.rows) {
+          const int cgs = __builtin_ctz(cg);
+          const size_t si = ((size_t)(traj0 + tr) * (a.cout >> cgs) + (co >> cgs)) * 2;
+          a.stats[si] = mean;
+          a.stats[si + 1] = rstd;
+        }
+      }
+    }
+    TRACE_STAMP(8);
+#pragma unroll
+    for (int rt = 0; rt < NRT; ++rt)
+#pragma unroll
+      for (int j = 0; j < NPR; ++j)
+#pragma unroll
+        for (int e = 0; e < PPT; ++e) {
+          float z = fmaf(acc[rt][j * PPT + e], scale[j], shift[j]);
+          if (a.gn) z = mish_fast_f(z);
+          acc[rt][j * PPT + e] = z + add[j];
+        }
+  }
+  __syncthreads();                          // K-loop image / raw tile fully read
+  write_tile();
+  __syncthreads();
+  TRACE_STAMP(9);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
+      a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
+#pragma unroll
+  for (int k = 0; k < NQ; ++k) {
+    f32x4 y = *reinterpret_cast<const f32x4*>(lds + (tid + 256 * k) * 4);
+    y += rv[k];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, flat_off(k, a.out_tstride, a.out_coff), 0, 0);
+  }
+  TRACE_STAMP(11);
+}
+
 template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
 struct ConvGeom {
   static constexpr int R = TB * L_OUT;
