@@ -169,6 +169,14 @@ def main():
             print("[bench] replanning at frame %d" % step_index, file=sys.stderr, flush=True)
             return _inner_get_action(obs, step_index, **kw)
         rollout.get_action = _get_action_with_progress
+        # the first map-encoder call compiles MIOpen kernels for minutes without output: keep a heartbeat
+        import threading
+
+        def _heartbeat():
+            while True:
+                time.sleep(45)
+                print("[bench] alive", file=sys.stderr, flush=True)
+        threading.Thread(target=_heartbeat, daemon=True).start()
         scene_ids = list(range(len(aps)))
         guidance = compute_heuristic_guidance(CLOSED_LOOP_HEURISTICS, env, scene_ids, None)
         calls_per_step = wl["sim_steps"] // wl["n_step_action"]

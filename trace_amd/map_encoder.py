@@ -110,8 +110,16 @@ class MapEncoder:
     convention of the reference's MapEncoder.forward (trace_helpers.py:219-229) without a global
     feature head (TRACE configs use the grid only: use_map_feat_global=False)."""
 
-    def __init__(self, state_dict, device="cuda:0"):
+    # From this many images per call the activations and weights go channels-last (NHWC): MIOpen then takes
+    # its NHWC implicit-GEMM fp32 kernels, 4.7x faster in steady state on MI355X (1024 images: 104 ms against
+    # 489 ms, scripts/prof_map_encoder.py; same result to 7e-6) -- at the price of ~90 s of kernel compilation
+    # the first time a process sees the shapes (MIOpen caches them on disk), which small calls do not repay.
+    CHANNELS_LAST_FROM = 1024
+
+    def __init__(self, state_dict, device="cuda:0", channels_last_from=None):
         self.device = torch.device(device)
+        self.channels_last_from = self.CHANNELS_LAST_FROM if channels_last_from is None else channels_last_from
+        self._p_nhwc = None
         p = {}
         for k, v in state_dict.items():
             if not k.startswith(PREFIX) or k.endswith("num_batches_tracked"):
@@ -125,7 +133,7 @@ class MapEncoder:
                    if k not in p]
         if missing:
             raise KeyError("map encoder weights missing from the state_dict: %s ..." % missing[:4])
-        self.p = p
+        self.p = self._p_nchw = p
         self._bn = {}
 
     # evaluation-mode BatchNorm as a per-channel affine (folded once)
@@ -167,8 +175,22 @@ class MapEncoder:
 
     @torch.no_grad()
     def __call__(self, image):
-        p = self.p
         x = image.to(device=self.device, dtype=torch.float32)
+        nhwc = self.device.type == "cuda" and x.shape[0] >= self.channels_last_from
+        if nhwc:
+            if self._p_nhwc is None:
+                self._p_nhwc = {k: (v.contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v)
+                                for k, v in self._p_nchw.items()}
+            x = x.contiguous(memory_format=torch.channels_last)
+        # the helper methods read self.p: point it at the layout of this call
+        self.p = self._p_nhwc if nhwc else self._p_nchw
+        try:
+            return self._forward(x)
+        finally:
+            self.p = self._p_nchw
+
+    def _forward(self, x):
+        p = self.p
         x = F.conv2d(x, p[_TRUNK + "conv1.weight"], None, 2, 3)
         x = F.relu(self._bn_apply(x, _TRUNK + "bn1"))
         x = F.max_pool2d(x, 3, 2, 1)
@@ -190,5 +212,5 @@ class MapEncoder:
         x = F.relu(out)
         x = F.conv2d(x, p[_DEC + "conv3.weight"], p[_DEC + "conv3.bias"])
         w, b = p[_DEC + "out_norm.weight"], p[_DEC + "out_norm.bias"]
-        x = F.layer_norm(x, tuple(w.shape), w, b, _LN_EPS)
+        x = F.layer_norm(x.contiguous(), tuple(w.shape), w, b, _LN_EPS)
         return None, x
