@@ -112,7 +112,7 @@ class MapEncoder:
 
     # From this many images per call the activations and weights go channels-last (NHWC): MIOpen then takes
     # its NHWC implicit-GEMM fp32 kernels, 4.7x faster in steady state on MI355X (1024 images: 104 ms against
-    # 489 ms, scripts/prof_map_encoder.py; same result to 7e-6) -- at the price of ~90 s of kernel compilation
+    # 489 ms, scripts/prof_map_encoder.py; max relative difference 3.9e-6) -- at the price of ~90 s of kernel compilation
     # the first time a process sees the shapes (MIOpen caches them on disk), which small calls do not repay.
     CHANNELS_LAST_FROM = 1024
 
