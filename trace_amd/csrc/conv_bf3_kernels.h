@@ -272,9 +272,22 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
         }
       }
       if (n + DIST < NT) load_a(n + DIST, (n + DIST) % NST);
-      if (n == 1 && (SPLITK || next >= 0)) {
+#ifndef TRACE_BF3_LOAD_SPREAD
+#define TRACE_BF3_LOAD_SPREAD 0   // row tiles between the global loads of two staging units of the next chunk (0: all at once)
+#endif
+      if constexpr (TRACE_BF3_LOAD_SPREAD == 0) {
+        if (n == 1 && (SPLITK || next >= 0)) {
 #pragma unroll
-        for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
+          for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
+        }
+      } else {
+        constexpr int SP = (NT - 2) / NUT < TRACE_BF3_LOAD_SPREAD ? ((NT - 2) / NUT > 0 ? (NT - 2) / NUT : 1) : TRACE_BF3_LOAD_SPREAD;
+        if (next >= 0 && n >= 1 && (n - 1) % SP == 0 && (n - 1) / SP < NUT) stage_load_unit(next, (n - 1) / SP);
+        if (next >= 0 && n == NT - 1) {
+#pragma unroll
+          for (int j = 0; j < NUT; ++j)
+            if (1 + j * SP > NT - 1) stage_load_unit(next, j);
+        }
       }
       if constexpr (SPLITK) {
         // the loads issued at n == 1 have landed by the last tiles of the chunk: split one staging unit per
