@@ -98,3 +98,50 @@ def test_profile_hooks_count_conv_launches(sampler):
     # Linears (1792 * 288, tabulated once per call / at create time) and the time MLP (2*32*128).
     per_row = fl.value / rows
     assert per_row == 2 * (60288512 - 2 * 64 * 52 - 1792 * 288 - 2 * 32 * 128), per_row
+
+
+def test_env_rasterize_and_social_group_reject_bad_arguments(sampler):
+    L = sampler.lib
+    dev = "cuda:0"
+    pose = torch.zeros(2, 3, device=dev)
+    soa = torch.zeros(2, dtype=torch.int32, device=dev)
+    boxes = torch.zeros(1, 1, 4, device=dev)
+    rfa = (C.c_float * 9)(12, 0, 56, 0, 12, 112, 0, 0, 1)
+    img = torch.empty(2, 2, 8, 8, device=dev)
+    drv = torch.empty(2, 8, 8, dtype=torch.uint8, device=dev)
+    ok = L.trace_env_rasterize(pose.data_ptr(), soa.data_ptr(), boxes.data_ptr(), 1, C.byref(rfa), img.data_ptr(), 2,
+                               drv.data_ptr(), 2, 8, 8, None)
+    assert ok == 0
+    torch.cuda.synchronize()
+    assert bool(drv.bool().all())                      # a zero-size box blocks nothing
+    rc = L.trace_env_rasterize(pose.data_ptr(), soa.data_ptr(), boxes.data_ptr(), 1, C.byref(rfa), img.data_ptr(), 2,
+                               drv.data_ptr(), 2, 8, 6, None)
+    assert rc == EINVAL and "multiple of 4" in _err(L)
+    rc = L.trace_env_rasterize(pose.data_ptr(), soa.data_ptr(), boxes.data_ptr(), 1, C.byref(rfa), None, 2,
+                               None, 2, 8, 8, None)
+    assert rc == EINVAL and "null" in _err(L)
+    skew = (C.c_float * 9)(12, 1, 56, 0, 12, 112, 0, 0, 1)
+    rc = L.trace_env_rasterize(pose.data_ptr(), soa.data_ptr(), boxes.data_ptr(), 1, C.byref(skew), img.data_ptr(), 2,
+                               drv.data_ptr(), 2, 8, 8, None)
+    assert rc == EINVAL and "scale + offset" in _err(L)
+    assert L.trace_env_rasterize(pose.data_ptr(), soa.data_ptr(), boxes.data_ptr(), 1, C.byref(rfa), img.data_ptr(), 2,
+                                 drv.data_ptr(), 0, 8, 8, None) == 0          # no agents: nothing to do
+    # social group: the members table must have the ABI's width
+    M, T = 4, 52
+    traj = torch.zeros(M, T, 6, device=dev)
+    loss = torch.zeros(M, device=dev)
+    wfa = torch.eye(3, device=dev).repeat(2, 1, 1).contiguous()
+    members = torch.full((2, 8), -1, dtype=torch.int32, device=dev)
+    lead = torch.zeros(2, dtype=torch.int32, device=dev)
+    scale = torch.ones(2, device=dev)
+    ws = torch.empty(M * T * 4, device=dev)
+    nbr = torch.empty(M * T, dtype=torch.int32, device=dev)
+    dist = torch.empty(M * T, device=dev)
+    rc = L.trace_guide_social_group(traj.data_ptr(), None, loss.data_ptr(), wfa.data_ptr(), members.data_ptr(), 8,
+                                    lead.data_ptr(), None, 1.5, scale.data_ptr(), 2, 2, T, ws.data_ptr(),
+                                    nbr.data_ptr(), dist.data_ptr(), None)
+    assert rc == EINVAL and "wide" in _err(L)
+    rc = L.trace_guide_social_group(traj.data_ptr(), None, loss.data_ptr(), wfa.data_ptr(), members.data_ptr(), 25,
+                                    lead.data_ptr(), None, 1.5, scale.data_ptr(), 2, 2, T, None,
+                                    nbr.data_ptr(), dist.data_ptr(), None)
+    assert rc == EINVAL and "null" in _err(L)
