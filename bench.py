@@ -11,12 +11,22 @@ configs[1]: target_pos guidance + classifier-free guidance (w=0.5), 256 agents x
 clean guidance, per GPU (weak scaling: every rank owns its own scenes; the only exchange is the
 all-gather of scores / selected plans at the end of each call).
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks ITSELF
+(a child `python -m torch.distributed.run ... bench.py ...`, started before this process touches the
+GPU), relays rank 0's JSON line and exits with the child's status.
+
+`--scaling strong` (with --workload cfg4_filter_only: BASELINE configs[3]) fixes the TOTAL work -- 512 scenes x
+32 agents x 20 samples -- and splits the scenes over the ranks with trace_amd.distributed.shard_scenes; each
+rank walks its scenes in sub-batches of 64 (scenes are independent units).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -98,6 +108,178 @@ def cpu_baseline(cfg, sd, wl_name, seconds_hint=20.0):
                       "full call" % (sum(aps), N, M, n_steps, cfg.n_diffusion_steps, dt)}
 
 
+def launch_ranks(n):
+    """Starts `n` ranks of this script under torch.distributed.run as a CHILD process (this process has
+    not touched the GPU: torch.cuda.device_count() does not initialise it on this image), relays rank 0's
+    JSON line to stdout and everything else to stderr, returns the child's exit status."""
+    backend = os.environ.get("TRACE_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.device_count() < n:
+        print("bench.py --gpus %d: only %d GPU(s) visible (TRACE_BENCH_BACKEND=gloo rehearses the "
+              "multi-process path with ranks sharing devices)" % (n, torch.cuda.device_count()), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in child.stdout:
+        out = out.rstrip("\n")
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            print(out, file=sys.stderr, flush=True)
+    rc = child.wait()
+    if rc == 0 and line is None:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        rc = 1
+    if line is not None and rc == 0:
+        print(line, flush=True)
+    return rc
+
+
+def conv_roofline(model, batch, N, wl, gen, device, n_prof_steps=5):
+    """Roofline block of the dominant kernel (conv_bf3_kernel: denoiser forward + input-VJP).
+    Two passes over the same n_prof_steps DDPM steps on the launch stream: pass A is bracketed by ONE pair of
+    HIP events (the undisturbed time of the steps); pass B brackets every conv launch with its own pair
+    (trace_profile_begin/end) and the whole pass with another.  Per-launch events stretch the pass by a few
+    per cent (two extra packets per launch), so the conv time reported is the conv SHARE of pass B applied to
+    the undisturbed time of pass A -- it cannot exceed the step it is part of."""
+    from trace_amd import _cabi
+    L = _cabi.lib()
+    kw = dict(class_free_guide_w=wl["w"], guide_clean=wl["clean"], n_steps=n_prof_steps, generator=gen,
+              apply_guidance=not wl.get("filter_only"))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    model.sampler(batch, N, **kw)                       # warm (buffers, kernel attributes)
+    torch.cuda.synchronize(device)
+    ev[0].record()
+    model.sampler(batch, N, **kw)
+    ev[1].record()
+    torch.cuda.synchronize(device)
+    _cabi.check(L.trace_profile_begin(200 * n_prof_steps), "trace_profile_begin")
+    ev[2].record()
+    model.sampler(batch, N, **kw)
+    ev[3].record()
+    ms, nl, fl = C.c_double(), C.c_int64(), C.c_double()
+    _cabi.check(L.trace_profile_end(C.byref(ms), C.byref(nl), C.byref(fl)), "trace_profile_end")
+    torch.cuda.synchronize(device)
+    t_a, t_b = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
+    share = min(ms.value / t_b, 1.0) if t_b > 0 else 0.0
+    conv_ms = share * t_a                               # conv time of the undisturbed pass
+    achieved = fl.value / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    # The conv kernel computes fp32 results on the bf16 matrix pipe: every algorithmic multiply-add
+    # is 6 bf16 MFMA multiply-adds (exact 3-way operand split, DESIGN.md section 5.1), so its MFMA
+    # roof in ALGORITHMIC FLOP/s is the dense bf16 peak / 6.  `achieved` counts algorithmic FLOPs.
+    bf16_peak, fp32_mfma_peak = 2500.0, 157.3
+    peak = bf16_peak / 6.0
+    # HBM bytes per launch cannot be counted from inside this process: the value comes from the
+    # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, corrected as
+    # MI355X_MICROARCH.md prescribes), null when that summary is absent.
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = float(json.load(f)["hbm_bytes_per_launch"])
+    return {"bound": "mfma",
+            "kernel": "conv_bf3_kernel (fp32 implicit-GEMM conv as 6 bf16-MFMA terms per product, fp32 accumulate)",
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "peak_is": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA terms per algorithmic product",
+            "frac_of_fp32_mfma_peak": achieved / fp32_mfma_peak,
+            "traffic": traffic, "launches": int(nl.value),
+            "avg_launch_us": conv_ms * 1e3 / max(nl.value, 1),
+            "conv_ms_per_ddpm_step": conv_ms / n_prof_steps,
+            "ddpm_step_ms": t_a / n_prof_steps,
+            "conv_share_of_step": share,
+            "per_launch_event_pass": {"sum_conv_ms": ms.value, "pass_ms": t_b}}
+
+
+def hbm_kernel_table(model, cfg, N, device, reps=20):
+    """Achieved GB/s of the HBM-bound kernels of the path (north_star: guidance and dynamics kernels against
+    the chip's 8 TB/s), each timed alone with HIP events on the launch stream over `reps` back-to-back
+    launches at the headline trajectory count (5120; the collision objectives on one dense 128-agent scene
+    x 20 samples = 2560, BASELINE configs[2]).  Bytes are the ALGORITHMIC bytes of SURVEY.md section 8(d)."""
+    from trace_amd import _cabi
+    from trace_amd._cabi import StepCoefs
+    from trace_amd.guidance import DiffuserGuidance
+    L, s = _cabi.lib(), model.sampler
+    T, st = cfg.horizon, torch.cuda.current_stream(device).cuda_stream
+    dyn = C.byref(s._dyn)
+    g = torch.Generator(device=device).manual_seed(5)
+    rows = []
+
+    def timed(name, bytes_per_traj, M, fn, note=""):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize(device)
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        gbs = bytes_per_traj * M / (us * 1e-6) / 1e9
+        rows.append({"kernel": name, "trajectories": M, "algorithmic_bytes": bytes_per_traj * M, "us": us,
+                     "GB/s": gbs, "frac_of_8TB/s": gbs / 8000.0, "note": note})
+
+    B = 256
+    M = B * N
+    aps = [32] * (B // 32)
+    batch = syn.make_batch(cfg, aps, seed=3, max_neighbors=4)
+    x = torch.randn(M, T, 6, device=device, generator=g)
+    a = torch.randn(M, T, 2, device=device, generator=g)
+    noise = torch.randn(M, T, 2, device=device, generator=g)
+    grad = torch.randn(M, T, 2, device=device, generator=g) * 1e-3
+    gtraj = torch.randn(M, T, 6, device=device, generator=g)
+    curr = torch.zeros(B, 4, device=device)
+    curr[:, 2] = 1.5
+    out6, out2 = torch.empty(M, T, 6, device=device), torch.empty(M, T, 2, device=device)
+    grid = torch.randn(B, 56, 56, cfg.map_grid_feature_dim, device=device, generator=g)
+    rfa = batch["raster_from_agent"].to(device).contiguous()
+    x_in = torch.zeros(M, 64, T, device=device)
+    sc = s._coefs(50)
+    csc = C.byref(sc)
+    Cg = cfg.map_grid_feature_dim
+    timed("map_query_kernel", 7072, M, lambda: L.trace_map_query(
+        x.data_ptr(), grid.data_ptr(), rfa.data_ptr(), x_in.data_ptr(), M, N, T, Cg, 56, 56, 64,
+        float(cfg.image_shape[2]), float(cfg.image_shape[1]), dyn, st),
+        "+26.6 KB/trajectory of cached grid gathers not counted")
+    timed("posterior_step_kernel", 2912, M, lambda: L.trace_posterior_step(
+        a.data_ptr(), grad.data_ptr(), x.data_ptr(), noise.data_ptr(), curr.data_ptr(), out6.data_ptr(),
+        out2.data_ptr(), M, N, T, 1, csc, dyn, st), "posterior + noise + rescale + 52-step unicycle scan")
+    timed("dyn_rollout_kernel", 1664, M, lambda: L.trace_dyn_rollout(
+        a.data_ptr(), curr.data_ptr(), out6.data_ptr(), M, N, T, 1, 0, dyn, st))
+    timed("dyn_adjoint_kernel", 2080, M, lambda: L.trace_dyn_adjoint(
+        a.data_ptr(), curr.data_ptr(), gtraj.data_ptr(), out2.data_ptr(), M, N, T, dyn, st))
+    traj = torch.empty(M, T, 6, device=device)
+    L.trace_dyn_rollout(a.data_ptr(), curr.data_ptr(), traj.data_ptr(), M, N, T, 1, 0, dyn, st)
+    plan = DiffuserGuidance(syn.target_pos_guidance(batch, aps, weight=30000.0, seed=3)).build_plan(batch, N, T, device)
+    gt = torch.zeros(M, T, 6, device=device)
+    timed("target_pos_kernel", 1252, M, lambda: plan.evaluate(traj, gt, st))
+    # collision objectives on the dense single scene of BASELINE configs[2]
+    Bc = 128
+    Mc = Bc * N
+    dense = syn.make_batch(cfg, [Bc], seed=4, dense=True, max_neighbors=4)
+    ac = torch.randn(Mc, T, 2, device=device, generator=g) * 0.5
+    currc = torch.zeros(Bc, 4, device=device)
+    currc[:, 2] = 1.5
+    trajc = torch.empty(Mc, T, 6, device=device)
+    L.trace_dyn_rollout(ac.data_ptr(), currc.data_ptr(), trajc.data_ptr(), Mc, N, T, 1, 0, dyn, st)
+    gtc = torch.zeros(Mc, T, 6, device=device)
+    for name, cfgs, note in (
+            ("agent_collision (world_pose_kernel + agent_collision_kernel<1>)",
+             [[{"name": "agent_collision", "weight": 1000.0, "params": {"num_disks": 1, "buffer_dist": 0.2}, "agents": None}]],
+             "ALU/latency-bound: 127 pair tests per (trajectory, step)"),
+            ("map_collision (map_collision_kernel + sum_over_time_kernel)",
+             [[{"name": "map_collision", "weight": 10.0, "params": {"num_points_lw": [10, 10]}, "agents": None}]],
+             "ALU-bound: 100 raster lookups + up to 10^4 matmul-form distances per (trajectory, step)")):
+        pl = DiffuserGuidance(cfgs).build_plan(dense, N, T, device)
+        timed(name, 1252, Mc, lambda pl=pl: pl.evaluate(trajc, gtc, st), note)
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,8 +294,13 @@ def main():
                          "launch-bound small batches such as cfg1")
     ap.add_argument("--host-inputs", action="store_true",
                     help="keep the observation batch in host memory (PCIe-inclusive rate; not the headline)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: every rank owns the workload's scenes; strong: 8x the workload's scenes in "
+                         "total (BASELINE configs[3]: 512 scenes), sharded scene-wise over the ranks")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -129,7 +316,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
@@ -188,23 +375,48 @@ def main():
             obs = env.get_observation()["agents"]
             return (obs["centroid"], stats)
     else:
-        aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, None if args.host_inputs else device)
-        B = sum(aps)
-        M = B * N
         model = DiffuserTrafficModel(cfg, sd, device)
         policy = PolicyWrapper.wrap_controller(model, num_action_samples=N, class_free_guide_w=wl["w"],
                                                guide_as_filter_only=bool(wl.get("filter_only")), guide_with_gt=False,
                                                guide_clean=wl["clean"])
-        if guidance is not None:
-            model.set_guidance(guidance, batch)
+        if args.scaling == "strong":
+            # total work fixed: 8x the per-GPU scene count (cfg4: 512 scenes), contiguous scene ranges per
+            # rank balanced by agent count; a rank walks its range in sub-batches of <= SUB scenes
+            from trace_amd.distributed import shard_scenes
+            from trace_amd.guidance import DiffuserGuidance
+            SUB = 64
+            total_scenes = 8 * wl["scenes"]
+            s0, s1 = shard_scenes([wl["agents"]] * total_scenes, world)[rank]
+            subs = []
+            for c0 in range(s0, s1, SUB):
+                wl_c = dict(wl, scenes=min(SUB, s1 - c0))
+                aps_c, batch_c, guid_c = build_inputs(cfg, wl_c, 1000 + c0, None)
+                batch_c.pop("image", None)                         # the map encoder's output is in the batch
+                if not args.host_inputs:
+                    batch_c = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch_c.items()}
+                subs.append((batch_c, DiffuserGuidance(guid_c, batch_c) if guid_c is not None else None, sum(aps_c)))
+                print("[bench] rank %d: scenes %d..%d ready" % (rank, c0, c0 + wl_c["scenes"]), file=sys.stderr, flush=True)
+            B = sum(b for _, _, b in subs)
+        else:
+            aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, None if args.host_inputs else device)
+            B = sum(aps)
+            if guidance is not None:
+                model.set_guidance(guidance, batch)
+            subs = [(batch, model.sampler.current_guidance, B)]
+        M = B * N
 
         def one_step(i):
-            action, info = policy.get_action(batch, step_index=i, generator=gen, use_graph=args.graph)
-            scores = info.get("guide_scores")
-            if scores is None:
-                scores = torch.zeros(B, N, device=device)
+            outs = []
+            for batch_c, guid_c, b_c in subs:
+                model.sampler.current_guidance = guid_c
+                action, info = policy.get_action(batch_c, step_index=i, generator=gen, use_graph=args.graph)
+                scores = info.get("guide_scores")
+                if scores is None:
+                    scores = torch.zeros(b_c, N, device=device)
+                outs.append((action.positions, action.yaws, scores, info["act_idx"]))
             # the path's one exchange step (RCCL all-gather; a no-op on one GPU)
-            return gather_actions(action.positions, action.yaws, scores, info["act_idx"])
+            return gather_actions(*[torch.cat(z, 0) for z in zip(*outs)])
+        batch = subs[0][0]
 
     def barrier():
         torch.cuda.synchronize(device)
@@ -227,39 +439,11 @@ def main():
     assert bool(torch.isfinite(out[0]).all()), "non-finite plan"
 
     roofline = None
+    hbm_kernels = None
     if not args.no_roofline and rank == 0 and not wl.get("closed_loop"):
-        # dominant kernel = conv_gemm_kernel (denoiser forward + input-VJP): per-launch HIP events on
-        # the launch stream over a short profiled stretch of the same workload
-        L = _cabi.lib()
-        n_prof_steps = 5
-        _cabi.check(L.trace_profile_begin(200 * n_prof_steps), "trace_profile_begin")
-        model.sampler(batch, N, class_free_guide_w=wl["w"], guide_clean=wl["clean"], n_steps=n_prof_steps,
-                      generator=gen)
-        ms, nl, fl = C.c_double(), C.c_int64(), C.c_double()
-        _cabi.check(L.trace_profile_end(C.byref(ms), C.byref(nl), C.byref(fl)), "trace_profile_end")
-        achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-        # The conv kernel computes fp32 results on the bf16 matrix pipe: every algorithmic multiply-add
-        # is 6 bf16 MFMA multiply-adds (exact 3-way operand split), so its MFMA
-        # roof in ALGORITHMIC FLOP/s is the dense bf16 peak / 6.  `achieved` counts algorithmic FLOPs.
-        bf16_peak, fp32_mfma_peak = 2500.0, 157.3
-        peak = bf16_peak / 6.0
-        # HBM bytes per launch cannot be counted from inside this process: the value comes from the
-        # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, corrected as
-        # MI355X_MICROARCH.md prescribes), null when that summary is absent.
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as f:
-                traffic = float(json.load(f)["hbm_bytes_per_launch"])
-        roofline = {"bound": "mfma",
-                    "kernel": "conv_bf3_kernel (fp32 implicit-GEMM conv as 6 bf16-MFMA terms per product, "
-                              "fp32 accumulate; a few stride-2 layers still on the fp32-MFMA conv_gemm_kernel)",
-                    "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                    "peak_is": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA terms per algorithmic product",
-                    "frac_of_fp32_mfma_peak": achieved / fp32_mfma_peak,
-                    "traffic": traffic, "launches": int(nl.value),
-                    "avg_launch_us": ms.value * 1e3 / max(nl.value, 1),
-                    "conv_ms_per_ddpm_step": ms.value / n_prof_steps}
+        model.sampler.current_guidance = subs[0][1]
+        roofline = conv_roofline(model, batch, N, wl, gen, device)
+        hbm_kernels = hbm_kernel_table(model, cfg, N, device)
     if world > 1:
         dist.barrier()
 
@@ -269,7 +453,7 @@ def main():
             "metric": "guided trajectory samples/sec (100 DDPM steps, 52-step horizon)",
             "value": total / elapsed, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32",
             "dtype_note": "fp32 results everywhere; the denoiser GEMMs evaluate each fp32 product as an exact 3-way "
                           "bf16 operand split (6 bf16-MFMA terms, fp32 accumulate; rms error equal to the fp32 "
@@ -282,10 +466,12 @@ def main():
                        "guidance": wl["guide"], "guide_clean": wl["clean"], "hip_graph": bool(args.graph),
                        "guide_as_filter_only": bool(wl.get("filter_only")),
                        "sampling_calls_per_step": calls_per_step,
+                       "total_agents": B * world if args.scaling == "weak" else 8 * wl["scenes"] * wl["agents"],
                        "parallelism": "scenes sharded over %d GPU(s), all-gather of scores/plans" % world},
         }
         if roofline is not None:
             res["roofline"] = roofline
+            res["hbm_kernels"] = hbm_kernels
         if world == 1 and not args.no_cpu_baseline and not wl.get("closed_loop"):
             res["cpu_baseline"] = cpu_baseline(cfg, sd, args.workload)
         print(json.dumps(res), flush=True)
