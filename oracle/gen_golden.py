@@ -49,6 +49,11 @@ def case_inputs(name):
         # feedback loop in the reference itself (a 1-ulp change of the initial noise moves the
         # final positions by 0.28 m); weights x0.01 keep the free-running comparison meaningful
         "noisy_tp_ac": dict(dense=True, w=0.0, guide="tp_ac", clean=False, apply=True, wscale=0.01),
+        # ... and the same at the eval configs' weights (target_pos 30000, agent_collision 1000,
+        # configs/eval/orca/target_pos_all_coll.json:158-176): teacher-forcing removes the feedback loop, so
+        # every reverse step started from the reference's own x_t is compared strictly; the free-running
+        # chain of this case is only checked for finiteness
+        "noisy_tp_ac_cfgw": dict(dense=True, w=0.0, guide="tp_ac", clean=False, apply=True),
     }[name]
     batch = syn.make_batch(cfg, aps, seed=1, extent=(0.9, 0.7, 1.75), dense=spec["dense"])
     guide = None
@@ -89,10 +94,14 @@ def case_inputs(name):
 
 
 CASES = ["unguided_w0", "cfg_w05", "clean_all", "noisy_all", "filter_only", "clean_misc",
-         "clean_tp_ac", "noisy_tp_ac"]
-FULL_DIFFUSION = {"unguided_w0", "clean_all", "noisy_all", "clean_misc", "clean_tp_ac", "noisy_tp_ac"}
+         "clean_tp_ac", "noisy_tp_ac", "noisy_tp_ac_cfgw"]
+FULL_DIFFUSION = {"unguided_w0", "clean_all", "noisy_all", "clean_misc", "clean_tp_ac", "noisy_tp_ac",
+                  "noisy_tp_ac_cfgw"}
 # cases whose guidance includes map_collision (compared through the stability mask, see tests)
 CHAOTIC = {"clean_all", "noisy_all"}
+# cases whose FREE-RUNNING chain is an unstable feedback loop in the reference itself (strict only when
+# teacher-forced)
+UNSTABLE = {"noisy_tp_ac_cfgw"}
 
 
 def _quiet():
@@ -249,10 +258,12 @@ def loss_component_configs(batch, aps):
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
-    comp = run_components()
-    np.savez_compressed(os.path.join(OUT, "components.npz"), **comp)
-    print("components:", len(comp), "arrays")
-    for name in CASES:
+    only = [a for a in sys.argv[1:] if a in CASES]          # `python -m oracle.gen_golden <case> ...`: those only
+    if not only:
+        comp = run_components()
+        np.savez_compressed(os.path.join(OUT, "components.npz"), **comp)
+        print("components:", len(comp), "arrays")
+    for name in (only or CASES):
         res = run_case(name)
         np.savez_compressed(os.path.join(OUT, "sample_%s.npz" % name), **res)
         print(name, {k: v.shape for k, v in res.items() if not k.startswith("guide_loss")})
