@@ -223,6 +223,24 @@ int trace_guide_agent_collision(const float* traj, float* grad_traj, float* loss
                                 const int* in_mask, const float* scale, int n_agents,
                                 int num_samp, int T, float* workspace, void* stream);
 
+/* trace_guide_agent_collision for callers that cannot allocate device memory (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.
+ * Same arguments and results as trace_guide_agent_collision minus `workspace`: the world poses go to a
+ * static device array of trace_static_scratch_bytes() (8 MiB) that every GPU the library runs on holds
+ * until the process ends.  Calls no hipMalloc / hipFree or allocating routine.  Rejects
+ * n_agents * num_samp * T * 4 floats beyond that size with TRACE_EINVAL.  All calls on one GPU share
+ * the array: calls that overlap on one GPU (two streams) race; calls in stream order do not.
+ * trace_static_scratch_init() resolves the array's device address for the CURRENT device (once per
+ * device; the entry point does it on first use otherwise) -- call it before a graph capture. */
+int trace_static_scratch_init(void);
+int64_t trace_static_scratch_bytes(void);
+int trace_guide_agent_collision_static(const float* traj, float* grad_traj, float* loss,
+                                       const float* world_from_agent, const float* radius,
+                                       const float* disk_x, int num_disks, float buffer_dist,
+                                       const int* scene_start, const int* scene_size,
+                                       const int* in_mask, const float* scale, int n_agents,
+                                       int num_samp, int T, void* stream);
+
 /* MapCollisionLoss (guidance_loss.py:382-464; tbsim/utils/metrics.py:216-240).
  *   drivable (n_agents, H, W) uint8 (bool); extent (n_agents,3); raster_from_agent (n_agents,3,3)
  *   local_pts (n_pts, 2): unit-box sample grid, cartesian_prod(linspace(-.5,.5,n_l),

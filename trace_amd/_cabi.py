@@ -77,6 +77,10 @@ PROTOTYPES = {
     "trace_guide_speed": (_I, [_P, _P, _P, _P, _P, _I, _F, _I, _I, _I, _P]),
     "trace_guide_agent_collision": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I,
                                          _I, _P, _P]),
+    "trace_static_scratch_init": (_I, []),
+    "trace_static_scratch_bytes": (_L, []),
+    "trace_guide_agent_collision_static": (_I, [_P, _P, _P, _P, _P, _P, _I, _F, _P, _P, _P, _P, _I, _I,
+                                                _I, _P]),
     "trace_guide_map_collision": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I,
                                        _P, _P]),
     "trace_env_rasterize": (_I, [_P, _P, _P, _I, C.POINTER(C.c_float * 9), _P, _I, _P, _I, _I, _I, _P]),

@@ -565,6 +565,66 @@ extern "C" int trace_guide_agent_collision(const float* traj, float* grad_traj, 
   return launch_status("agent_collision_kernel");
 }
 
+// ---- the entry point that allocates nothing -------------------------------------------------
+// World poses of trace_guide_agent_collision (its `workspace` argument) kept in a file-scope device
+// array instead, for callers that cannot allocate.  `scratch` is a host-side stand-in here: the
+// device address is looked up once per device with hipGetSymbolAddress and only that pointer is
+// ever handed to kernels.
+namespace {
+constexpr int kStaticScratchFloats = 2 * 1024 * 1024;             // 8 MiB per GPU
+static __device__ __align__(256) float scratch[kStaticScratchFloats];
+constexpr int kMaxDevices = 64;
+float* g_scratch_ptr[kMaxDevices] = {};                          // per device, resolved on first use
+
+int static_scratch(float** out) {
+  int dev = -1;
+  TRACE_CHECK_HIP(hipGetDevice(&dev));
+  TRACE_REQUIRE(dev >= 0 && dev < kMaxDevices, "device ordinal %d outside 0..%d", dev, kMaxDevices - 1);
+  float* p = __atomic_load_n(&g_scratch_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!p) {
+    void* sym = nullptr;
+    TRACE_CHECK_HIP(hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch)));
+    TRACE_REQUIRE(sym != nullptr, "hipGetSymbolAddress returned a null address for the static scratch");
+    p = reinterpret_cast<float*>(sym);
+    __atomic_store_n(&g_scratch_ptr[dev], p, __ATOMIC_RELEASE);  // every thread resolves the same address
+  }
+  *out = p;
+  return TRACE_OK;
+}
+}  // namespace
+
+extern "C" int trace_static_scratch_init(void) {
+  float* p = nullptr;
+  return static_scratch(&p);
+}
+
+extern "C" int64_t trace_static_scratch_bytes(void) { return (int64_t)kStaticScratchFloats * sizeof(float); }
+
+extern "C" int trace_guide_agent_collision_static(const float* traj, float* grad_traj, float* loss,
+                                                  const float* world_from_agent, const float* radius,
+                                                  const float* disk_x, int num_disks,
+                                                  float buffer_dist, const int* scene_start,
+                                                  const int* scene_size, const int* in_mask,
+                                                  const float* scale, int n_agents, int num_samp,
+                                                  int T, void* stream) {
+  TRACE_REQUIRE(n_agents >= 0 && num_samp > 0 && T > 0 && T <= 64,
+                "trace_guide_agent_collision_static: bad shape n_agents=%d num_samp=%d T=%d", n_agents,
+                num_samp, T);
+  const long long need = (long long)n_agents * num_samp * T * 4;
+  TRACE_REQUIRE(need <= (long long)kStaticScratchFloats,
+                "trace_guide_agent_collision_static: %d agents x %d samples x %d steps need %lld scratch "
+                "floats, the static scratch holds %d (use trace_guide_agent_collision with a workspace)",
+                n_agents, num_samp, T, need, kStaticScratchFloats);
+  float* ws = nullptr;
+  int rc = static_scratch(&ws);
+  if (rc) return rc;
+  // every element the second kernel reads is written by the first one of the same call: nothing
+  // of the previous call's contents has to be cleared
+  return trace_guide_agent_collision(traj, grad_traj, loss, world_from_agent, radius, disk_x, num_disks,
+                                     buffer_dist, scene_start, scene_size, in_mask, scale, n_agents,
+                                     num_samp, T, ws, stream);
+}
+
 extern "C" int trace_guide_map_collision(const float* traj, float* grad_traj, float* loss,
                                          const uint8_t* drivable, const float* extent,
                                          const float* raster_from_agent, const float* local_pts,
