@@ -165,3 +165,151 @@ def test_image_only_batch_runs_through_the_map_encoder():
     b = model.sampler(b_feat, **kw)["pred_traj_scaled"].cpu()
     assert torch.isfinite(a).all()
     assert float(((a - b).abs() / (1.0 + b.abs())).max()) < 5e-3
+
+
+def test_dense_scene_map_and_agent_collision_step_matches_the_oracle():
+    """configs[2] at full size with BOTH collision objectives (configs/eval/orca/target_pos_all_coll.json
+    :158-176 weights): one clean-guidance reverse step of the 128-agent scene x 20 samples (2560
+    trajectories) against the oracle.  The map-collision gradient of the reference is chaotic at the ulp
+    level, so trajectories are compared where the oracle reproduces itself under
+    ~1-ulp perturbations of x_t (stability mask); the observed numbers are asserted with a margin."""
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 0)
+    aps, N = [128], 20
+    batch = syn.make_batch(cfg, aps, seed=7, dense=True, max_neighbors=16)
+    guidance = syn.collision_guidance(aps, agent_weight=1000.0, map_weight=10.0, num_disks=1)
+    B = sum(aps)
+    x0 = _x_init(cfg, batch, B, N, 8)
+    noise = torch.randn(1, B * N, cfg.horizon, 2, generator=torch.Generator().manual_seed(9))
+    s = TraceSampler(cfg, sd, DEV)
+    s.set_guidance(guidance, batch)
+    out = s.forward(batch, num_samp=N, class_free_guide_w=0.0, guide_clean=True, x_init=x0, steps=[40],
+                    noise_steps=noise, return_guidance_losses=True)
+    got = out["pred_traj_scaled"].reshape(B * N, cfg.horizon, 6).cpu()
+    assert bool(torch.isfinite(got).all())
+    o = orc.OracleSampler(cfg, sd)
+    o.set_guidance(guidance)
+    aux = o.repeat_aux(orc.get_aux_info(o.sd, cfg, batch, False), N)
+    tt = torch.full((B * N,), 40, dtype=torch.long)
+    ref, per = o.p_sample(x0, tt, batch, aux, N, 0.0, noise[0], True, True, eval_final=True)
+    assert float(torch.nan_to_num(per["agent_collision_scene_000_00"]).max()) > 0
+    assert float(torch.nan_to_num(per["map_collision_scene_000_01"]).max()) > 0
+    rel_of = lambda a: ((a - ref).abs() / (1.0 + ref.abs())).amax(dim=(1, 2))
+    stable = torch.ones(B * N, dtype=torch.bool)
+    pg = torch.Generator().manual_seed(10)
+    for _ in range(2):
+        xp = x0 * (1 + (torch.rand(x0.shape, generator=pg) - 0.5) * 6e-7)
+        op, _ = o.p_sample(xp, tt, batch, aux, N, 0.0, noise[0], True, True, eval_final=False)
+        stable &= rel_of(op) < 5e-5
+    rel = rel_of(got)
+    n_stable, n_out = int(stable.sum()), int((stable & (rel > 1e-4)).sum())
+    print("cfg3 full size, agent + map collision: stable %d / %d trajectories, HIP outliers on stable ones %d, "
+          "worst stable rel %.2e" % (n_stable, B * N, n_out, float(rel[stable].max())))
+    # observed: 2554 / 2560 stable, 0 outliers, worst stable 4.8e-5
+    assert n_stable >= 0.9 * B * N, n_stable
+    assert n_out <= 0.005 * n_stable, (n_out, n_stable)
+    # the filtering losses of the step's output (forward values are not chaotic)
+    gl = out["predictions"]["guide_losses"]
+    for k in ("agent_collision_scene_000_00", "map_collision_scene_000_01"):
+        a, b = gl[k].cpu(), per[k]
+        close = (a - b).abs() <= 1e-3 + 1e-2 * b.abs()
+        assert float(close.float().mean()) > 0.97, (k, float(close.float().mean()))
+
+
+def _bits_equal(a, b):
+    return torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+
+
+def test_cfg4_per_gpu_shape_filter_only_properties():
+    """configs[3] per-GPU shape: 64 scenes x 32 agents x 20 samples = 40,960 trajectories, guidance as
+    filter only (target_pos + agent + map collision evaluated on the final sample).  Size-independent
+    properties: finite, bit-deterministic, and a scene run alone reproduces its slice (the size at which the
+    32-bit offset arithmetic of the conv kernels matters)."""
+    from trace_amd.distributed import slice_batch, slice_guidance
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 0)
+    aps, N = [32] * 64, 20
+    batch = syn.make_batch(cfg, aps, seed=300, max_neighbors=8)
+    batch.pop("image")
+    guidance = syn.merge_guidance(syn.target_pos_guidance(batch, aps, weight=30000.0, seed=300),
+                                  syn.collision_guidance(aps, agent_weight=1000.0, map_weight=10.0, num_disks=1))
+    B = sum(aps)
+    x0 = _x_init(cfg, batch, B, N, 15)
+    noise = torch.randn(len(STEPS), B * N, cfg.horizon, 2, generator=torch.Generator().manual_seed(16))
+    s = TraceSampler(cfg, sd, DEV)
+    s.set_guidance(guidance, batch)
+    kw = dict(num_samp=N, class_free_guide_w=0.0, apply_guidance=False, guide_clean=True, steps=STEPS,
+              return_guidance_losses=True)
+
+    def run(smp, b, x, nz):
+        out = smp.forward(b, x_init=x, noise_steps=nz, **kw)
+        idx = out["guidance_plan"].choose_action(out["guidance_layer_losses"]).cpu()
+        losses = {k: out["predictions"]["guide_losses"][k].cpu() for k in out["predictions"]["guide_losses"].keys()}
+        return out["pred_traj_scaled"].reshape(-1, cfg.horizon, 6).cpu(), losses, idx
+
+    r1, l1, i1 = run(s, batch, x0, noise)
+    assert r1.shape[0] == 40960 and bool(torch.isfinite(r1).all())
+    r2, l2, i2 = run(s, batch, x0, noise)
+    assert torch.equal(r1, r2) and torch.equal(i1, i2)
+    assert all(_bits_equal(l1[k], l2[k]) for k in l1)
+    for scenes in ((0, 1), (63, 64)):
+        sub, (a0, a1) = slice_batch(batch, aps, scenes)
+        s1 = TraceSampler(cfg, sd, DEV)
+        s1.set_guidance(slice_guidance(guidance, scenes), sub)
+        r, l, i = run(s1, sub, x0[a0 * N:a1 * N], noise[:, a0 * N:a1 * N])
+        ref = r1[a0 * N:a1 * N]
+        rel = float(((r - ref).abs() / (1.0 + ref.abs())).max())
+        assert rel < 2e-5, (scenes, rel)
+        # selection is per scene: the scene alone picks what it picked inside the batch, unless two samples'
+        # scores tie to within the conditioning MLPs' batch-size-dependent rounding
+        assert float((i == i1[a0:a1]).float().mean()) >= 0.9, (scenes, i, i1[a0:a1])
+
+
+def test_cfg5_per_gpu_shape_replan_properties():
+    """configs[4] per-GPU shape: one replanning call on the observation of 128 scenes x 32 agents built by
+    the device environment, 10 samples (40,960 trajectories with saved activations for the input-VJP),
+    global_target_pos + agent + map collision, clean guidance.  Finite, bit-deterministic, and a scene run
+    alone reproduces its slice on the trajectories the chaotic map-collision gradient leaves alone."""
+    from trace_amd.distributed import slice_batch, slice_guidance
+    from trace_amd.scene_edit import compute_heuristic_guidance
+    from trace_amd.sim_env import SceneBatchEnv
+    cfg = ModelConfig()
+    sd = random_state_dict(cfg, 0)
+    aps, N = [32] * 128, 10
+    heur = [{"name": "agent_collision", "weight": 1000.0, "params": {"num_disks": 1, "buffer_dist": 0.2}},
+            {"name": "map_collision", "weight": 10.0, "params": {"num_points_lw": [10, 10]}},
+            {"name": "global_target_pos", "weight": 10000.0,
+             "params": {"target_time": 100, "urgency": 0.7, "pref_speed": 1.25, "min_progress_dist": 0.5, "dt": 0.1}}]
+    env = SceneBatchEnv(cfg, aps, device=DEV, seed=21, num_simulation_steps=100)
+    scene_ids = list(range(len(aps)))
+    guidance = compute_heuristic_guidance(heur, env, scene_ids, None)
+    obs = dict(env.get_observation()["agents"])
+    B = sum(aps)
+    assert obs["image"].shape[0] == B
+    obs.pop("image")
+    g = torch.Generator().manual_seed(22)
+    obs["map_grid_feat"] = torch.randn(B, cfg.map_grid_feature_dim, *cfg.grid_hw, generator=g).to(DEV)
+    cpu_obs = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in obs.items()}
+    x0 = _x_init(cfg, cpu_obs, B, N, 23)
+    noise = torch.randn(len(STEPS), B * N, cfg.horizon, 2, generator=torch.Generator().manual_seed(24))
+    kw = dict(num_samp=N, class_free_guide_w=0.0, guide_clean=True, steps=STEPS)
+    s = TraceSampler(cfg, sd, DEV)
+    s.set_guidance(guidance, obs)
+    r1 = s.forward(obs, x_init=x0, noise_steps=noise, **kw)["pred_traj_scaled"].reshape(B * N, -1, 6).cpu()
+    assert r1.shape[0] == 40960 and bool(torch.isfinite(r1).all())
+    r2 = s.forward(obs, x_init=x0, noise_steps=noise, **kw)["pred_traj_scaled"].reshape(B * N, -1, 6).cpu()
+    assert torch.equal(r1, r2)
+    scenes = (77, 78)
+    sub, (a0, a1) = slice_batch(obs, aps, scenes)
+    s1 = TraceSampler(cfg, sd, DEV)
+    s1.set_guidance(slice_guidance(guidance, scenes), sub)
+    r = s1.forward(sub, x_init=x0[a0 * N:a1 * N], noise_steps=noise[:, a0 * N:a1 * N], **kw)
+    r = r["pred_traj_scaled"].reshape((a1 - a0) * N, -1, 6).cpu()
+    ref = r1[a0 * N:a1 * N]
+    rel = ((r - ref).abs() / (1.0 + ref.abs())).amax(dim=(1, 2))
+    print("cfg5 shape, scene alone vs slice: %d / %d trajectories within 2e-5, worst %.2e"
+          % (int((rel < 2e-5).sum()), rel.numel(), float(rel.max())))
+    # observed 279 / 320 (worst 3.4e-4): the conditioning MLPs' rocBLAS kernels round differently at 32 and at 4096
+    # rows, and the map-collision arg-min flips on such differences (DESIGN.md section 5.2)
+    assert float((rel < 2e-5).float().mean()) >= 0.75, float((rel < 2e-5).float().mean())
+    assert float(rel.max()) < 5e-3, float(rel.max())

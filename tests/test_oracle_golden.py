@@ -1,5 +1,6 @@
 """Pins the CPU oracle (oracle/trace_oracle.py) against golden vectors emitted by the
-reference itself (oracle/gen_golden.py).  CPU only."""
+reference itself (oracle/gen_golden.py).  CPU only.  Every comparison is BIT-EXACT (rtol = atol = 0):
+the oracle runs the same ATen ops in the same order on the same torch build as the reference did."""
 import os
 
 import numpy as np
@@ -19,7 +20,7 @@ def _load(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 
 
-def _close(a, b, rtol=1e-5, atol=1e-6):
+def _close(a, b, rtol=0, atol=0):
     a, b = np.asarray(a), np.asarray(b)
     assert a.shape == b.shape, (a.shape, b.shape)
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True)
@@ -62,8 +63,8 @@ def test_dynamics_forward_and_grad(comp, setup):
     st = orc.unicycle_rollout(cfg, init, act)
     wgt = torch.randn(st.shape, generator=g)
     gr, = torch.autograd.grad((st * wgt).sum(), act)
-    _close(st.detach(), comp["dyn/states"], 1e-6, 1e-6)
-    _close(gr, comp["dyn/grad"], 1e-6, 1e-6)
+    _close(st.detach(), comp["dyn/states"], 0, 0)
+    _close(gr, comp["dyn/grad"], 0, 0)
     # the fixture must exercise every clip
     a = act.detach()
     assert (a[..., 0] > cfg.acce_bound[1]).any() and (a[..., 0] < cfg.acce_bound[0]).any()
@@ -86,8 +87,8 @@ def test_map_query_and_unet(comp, setup):
     y = orc.unet_forward(sd, cfg, xin, aux["cond_feat"], t)
     wy = torch.randn(y.shape, generator=g)
     gx, = torch.autograd.grad((y * wy).sum(), xin)
-    _close(y.detach(), comp["unet/out"], 1e-6, 1e-6)
-    _close(gx, comp["unet/grad_in"], 1e-5, 1e-6)
+    _close(y.detach(), comp["unet/out"], 0, 0)
+    _close(gx, comp["unet/grad_in"], 0, 0)
 
 
 def test_guidance_objectives(comp, setup):
@@ -100,10 +101,10 @@ def test_guidance_objectives(comp, setup):
         guid.update(global_t=7)
         tot, per = guid.loss(tr, batch)
         gt, = torch.autograd.grad(tot, tr)
-        _close(tot.detach(), comp["loss/%s/total" % lname], 1e-6, 1e-7)
-        _close(gt, comp["loss/%s/grad" % lname], 1e-5, 1e-7)
+        _close(tot.detach(), comp["loss/%s/total" % lname], 0, 0)
+        _close(gt, comp["loss/%s/grad" % lname], 0, 0)
         for k, v in per.items():
-            _close(v, comp["loss/%s/per/%s" % (lname, k)], 1e-6, 1e-7)
+            _close(v, comp["loss/%s/per/%s" % (lname, k)], 0, 0)
         active[lname] = float(gt.abs().max())
     # every objective must be active in the fixture (non-trivial gradient)
     for k, v in active.items():
@@ -121,14 +122,14 @@ def test_sampler_end_to_end(name):
                        noise_init=c["noise_init"], noise_steps=c["noise_steps"])
     s = res["samples"]
     if name in FULL_DIFFUSION:
-        _close(s["diffusion_steps"], gold["diffusion_steps"], 2e-5, 2e-5)
+        _close(s["diffusion_steps"], gold["diffusion_steps"], 0, 0)
     else:
-        _close(s["diffusion_steps"][:, :, :, -1], gold["diffusion_steps_last"], 2e-5, 2e-5)
-    _close(s["positions"], gold["positions"], 2e-5, 2e-5)
-    _close(s["yaws"], gold["yaws"], 2e-5, 2e-5)
+        _close(s["diffusion_steps"][:, :, :, -1], gold["diffusion_steps_last"], 0, 0)
+    _close(s["positions"], gold["positions"], 0, 0)
+    _close(s["yaws"], gold["yaws"], 0, 0)
     if c["guidance"] is not None:
         for k, v in s["guide_losses"].items():
-            _close(v, gold["guide_loss/" + k], 1e-4, 1e-6)
+            _close(v, gold["guide_loss/" + k], 0, 0)
         assert np.array_equal(res["act_idx"].numpy(), gold["act_idx"])
 
 
