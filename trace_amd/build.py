@@ -14,10 +14,11 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libtrace_hip.so")
 
 # (source, extra flags).  steps/guidance hold the op-exact elementwise chains: no FMA contraction.
-# unet.hip: no SLP vectorisation -- packed-fp32 VALU (v_pk_add_f32 ...) that the vectoriser forms from
-# the two-rows-per-thread GroupNorm statistics feeds the DPP butterfly, and on gfx950 a DPP read issued
-# shortly after a packed write saw stale lanes 48..63 (run-to-run differences at two workgroups per
-# CU, found with scripts/dbg_determinism.py / dbg_ws_diff.py); packed fp32 is also slower beside MFMAs.
+# unet.hip: no SLP vectorisation.  With it the two GroupNorm rows a thread owns are summed as v_pk_add_f32
+# chains whose operands are v_mov pairs of LDS-returned registers, and on gfx950 lanes 48..63 of those
+# sums then differed from run to run (five build variants A/B'd on the box).
+# The row sums are additionally fenced in the source (conv_kernels.h), so either guard alone is enough;
+# packed fp32 is also an anti-lever beside MFMAs (MI355X_MICROARCH.md).
 SOURCES = [
     ("unet.hip", ["-fno-slp-vectorize"]),
     ("steps.hip", ["-ffp-contract=off"]),

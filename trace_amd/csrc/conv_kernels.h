@@ -118,9 +118,6 @@ __device__ __forceinline__ float dpp_add(float v, int ctrl_tag) {
 
 template <int NP>
 __device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
-  // keep a few idle issue slots between whatever produced v[] and the first cross-lane read (see the
-  // note on packed-fp32 producers in trace_amd/build.py)
-  asm volatile("s_nop 4");
   if (cg > 1) {
 #pragma unroll
     for (int j = 0; j < NP; ++j) v[j] = dpp_add(v[j], 1);
@@ -325,6 +322,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
           t1 += d;
           t2 = fmaf(d, x, t2);
         }
+        asm volatile("" : "+v"(t1), "+v"(t2));      // same guard as the forward moments
         s1[j] = t1;
         s2[j] = t2;
       }
@@ -430,13 +428,18 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
         float sacc = 0.f;
 #pragma unroll
         for (int i = 0; i < L_OUT; ++i) sacc += v[j][i];
-        const float rm = sacc * (1.f / (float)L_OUT);
+        float rm = sacc * (1.f / (float)L_OUT);
         float q = 0.f;
 #pragma unroll
         for (int i = 0; i < L_OUT; ++i) {
           const float d = v[j][i] - rm;
           q = fmaf(d, d, q);
         }
+        // Each row's moments stay in registers of their own: with the two rows of a thread SLP-packed
+        // (v_pk_add_f32 chains fed by v_mov pairs of just-returned LDS registers behind partial
+        // s_waitcnt lgkmcnt(N)) lanes 48..63 of the sums differed from run to run on gfx950 (DESIGN.md
+        // section 5.1, "run-to-run differences"); the opaque use keeps the sums scalar whatever the flags.
+        asm volatile("" : "+v"(rm), "+v"(q));
         rmean[j] = rm;
         m2[j] = q;
         gs[j] = rm;
