@@ -104,6 +104,12 @@ int trace_unet_backward_input(trace_unet* u, const float* grad_pred, int rows, f
 int trace_profile_begin(int max_launches);
 int trace_profile_end(double* total_ms, int64_t* launches, double* total_flops);
 
+#ifdef TRACE_CONV_STAMPS
+/* Diagnostic builds only (scripts/stamps.py builds a second library with -DTRACE_CONV_STAMPS): conv launch
+ * number `launch_index` after this call writes 16 s_memtime stamps per workgroup into `buf` (device). */
+void trace_debug_stamps(void* buf, int launch_index);
+#endif
+
 /* ------------------------------------------------------------- sampler steps ---- */
 /* Constants of the sampler: normalisation (tbsim/models/trace.py:415-447), unicycle bounds
  * (tbsim/dynamics/unicycle.py:7-18), dt. */
@@ -185,7 +191,8 @@ int trace_posterior_step(const float* x0, const float* grad, const float* x, con
  * grad_traj (M,T,6) (may be NULL: value only) and write the unweighted per-trajectory loss
  * into loss (M) for trajectories of active agents (others untouched).  Per-agent tables have
  * n_agents rows; `scale[a]` = weight / (|mask| * num_samp) is the factor of
- * DiffuserGuidance.compute_guidance_loss (tbsim/utils/guidance_loss.py:919), 0 = inactive. */
+ * DiffuserGuidance.compute_guidance_loss (tbsim/utils/guidance_loss.py:919); NEGATIVE = agent not covered
+ * (loss untouched, no gradient); 0 = covered with weight 0 (loss written, zero gradient). */
 
 /* TargetPosLoss (guidance_loss.py:523-540): target (n_agents,2), t_min (n_agents) first step. */
 int trace_guide_target_pos(const float* traj, float* grad_traj, float* loss, const float* target,

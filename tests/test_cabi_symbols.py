@@ -16,6 +16,8 @@ def _header_functions():
     """name -> number of parameters, parsed from the header text."""
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)          # comments
+    # declarations of diagnostic builds only (-DTRACE_CONV_STAMPS): not part of the shipped library
+    text = re.sub(r"#ifdef TRACE_CONV_STAMPS.*?#endif", "", text, flags=re.S)
     text = re.sub(r"typedef\s+struct\s*\{.*?\}\s*\w+\s*;", "", text, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(trace_\w+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):

@@ -372,3 +372,40 @@ def test_sampler_with_social_group_guidance(env):
     assert err < 1e-4, err
     gl = out["predictions"]["guide_losses"]
     assert any(k.startswith("social_group") for k in gl.keys())
+
+
+def test_split_agent_collision_configs_and_weight_zero_guides(env):
+    """Two agent_collision configs with equal parameters and disjoint `agents` lists in ONE scene (the reference
+    detaches the other config's agents, guidance_loss.py:272-282: cross-config pairs get the gradient once, not
+    twice), and a guide of weight 0 (its loss is still evaluated, reported and used for selection)."""
+    from trace_amd.guidance import DiffuserGuidance
+    cfg, aps, batch = env["cfg"], env["aps"], env["batch"]
+    comp = dict(np.load(os.path.join(GOLDEN, "components.npz")))
+    traj0 = torch.tensor(comp["loss/traj"])
+    B, N, T = traj0.shape[:3]
+    ac = lambda w, agents: {"name": "agent_collision", "weight": w, "params": {"num_disks": 2, "buffer_dist": 0.3},
+                            "agents": agents}
+    cfgs = [[ac(1.5, [0, 1]), ac(2.0, [2])],
+            [{"name": "target_pos", "weight": 0.0, "params": {"target_pos": [[3.0, 0.5], [2.0, -1.0]]}, "agents": None},
+             ac(0.7, None)]]
+    tr = traj0.clone().requires_grad_()
+    guid = orc.Guidance(cfgs)
+    tot, per = guid.loss(tr, batch)
+    gref, = torch.autograd.grad(tot, tr)
+    plan = DiffuserGuidance(cfgs).build_plan(batch, N, T, DEV)
+    assert sum(ly["kind"] == "agent_collision" for ly in plan.layers) == 2       # scene 0's two configs kept apart
+    td = traj0.reshape(B * N, T, 6).to(DEV).contiguous()
+    gt = torch.zeros(B * N, T, 6, device=DEV)
+    ll = plan.evaluate(td, gt, None)
+    losses = plan.guide_losses(ll)
+    assert float(torch.nan_to_num(per["target_pos_scene_001_00"]).abs().max()) > 0
+    for k, v in per.items():
+        got = losses[k].cpu()
+        assert torch.equal(torch.isnan(got), torch.isnan(v)), k
+        assert _rel(torch.nan_to_num(got), torch.nan_to_num(v)) < 1e-4, k
+    scale = float(gref.abs().max())
+    err = float((gt.cpu().reshape(B, N, T, 6) - gref).abs().max()) / scale
+    assert scale > 0 and err < 2e-4, err
+    idx = plan.choose_action(ll).cpu()
+    ref_idx = orc.choose_action_from_guidance(B, guid.names(), {k: v.detach() for k, v in per.items()})
+    assert torch.equal(idx, ref_idx), (idx, ref_idx)

@@ -97,6 +97,24 @@ def test_plan_merges_disjoint_configs_into_layers_and_normalises_by_mask():
         "target_pos_scene_002_00", "agent_collision_scene_002_01"]
 
 
+def test_scene_coupled_configs_of_one_scene_never_share_a_launch():
+    """Two agent_collision configs with equal parameters and disjoint agents in ONE scene stay separate layers
+    (the pair kernel doubles a pair's gradient inside one config only, guidance_loss.py:272-282); configs of
+    different scenes still merge.  Agents a layer does not cover carry scale -1, covered ones weight/(|mask| N)
+    even when the weight is 0."""
+    aps, N = [3, 2], 4
+    ac = lambda w, agents: {"name": "agent_collision", "weight": w, "params": {"num_disks": 2, "buffer_dist": 0.2},
+                            "agents": agents}
+    configs = [[ac(1.0, [0, 1]), ac(0.0, [2])], [ac(3.0, None)]]
+    _, plan = _plan(aps, N, configs)
+    layers = [ly for ly in plan.layers if ly["kind"] == "agent_collision"]
+    assert len(layers) == 2
+    assert layers[0]["mask"].tolist() == [True, True, False, True, True]
+    assert layers[1]["mask"].tolist() == [False, False, True, False, False]
+    assert layers[1]["tables"]["scale"].tolist() == [-1.0, -1.0, 0.0, -1.0, -1.0]
+    assert torch.allclose(layers[0]["tables"]["scale"], torch.tensor([1 / 8, 1 / 8, -1.0, 3 / 8, 3 / 8]))
+
+
 def test_target_speed_list_form_raises_like_the_reference_would():
     aps = [2]
     bad = [[{"name": "target_speed", "weight": 1.0,
@@ -133,6 +151,11 @@ def test_choose_action_matches_oracle_selection(seed):
     ref = orc.choose_action_from_guidance(B, names, losses)
     got = plan.choose_action(layer_losses)
     assert torch.equal(got, ref), (got, ref)
+    # the public free function on the per-guide NaN-padded losses (guidance_loss.py:15-41), objects or dicts
+    from trace_amd.guidance import choose_action_from_guidance
+    preds = {"positions": torch.zeros(B, N, cfg.horizon, 2)}
+    assert torch.equal(choose_action_from_guidance(preds, batch, g.guide_configs, losses), ref)
+    assert torch.equal(choose_action_from_guidance(preds, batch, configs, losses), ref)
     # NaN outside each guide's mask (guidance_loss.py:916-918)
     if empty_scene != 1:
         v = losses["min_speed_scene_001_01"]
@@ -184,6 +207,8 @@ def test_compat_package_exposes_the_reference_import_paths():
         assert importlib.import_module("tbsim.algos.algos").DiffuserTrafficModel is policy.DiffuserTrafficModel
         gl = importlib.import_module("tbsim.utils.guidance_loss")
         assert gl.DiffuserGuidance is DiffuserGuidance
+        from trace_amd import guidance as tg
+        assert gl.choose_action_from_guidance is tg.choose_action_from_guidance
     finally:
         sys.path.remove(compat)
         for m in [m for m in sys.modules if m == "tbsim" or m.startswith("tbsim.")]:

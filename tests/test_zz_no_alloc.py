@@ -30,7 +30,7 @@ def _inputs(n_scenes, per_scene, N, D, seed):
     start = (torch.arange(B) // per_scene * per_scene).int()
     size = torch.full((B,), per_scene, dtype=torch.int32)
     in_mask = (torch.rand(B, generator=g) > 0.2).int()
-    scale = torch.where(in_mask > 0, torch.full((B,), 1000.0 / (per_scene * N)), torch.zeros(B))
+    scale = torch.where(in_mask > 0, torch.full((B,), 1000.0 / (per_scene * N)), torch.full((B,), -1.0))
     dev = lambda t: t.contiguous().to(DEV)
     return dict(traj=dev(traj), wfa=dev(wfa), radius=dev(radius), disk_x=dev(disk_x), start=dev(start),
                 size=dev(size), in_mask=dev(in_mask), scale=dev(scale), B=B, N=N, D=D, M=M)

@@ -35,6 +35,16 @@ bool prof_active();
 void prof_pre(hipStream_t st);
 void prof_post(hipStream_t st, double flops);
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to a (kernel, device) pair: `done` is one bit
+// per device ordinal, owned by the launcher of one kernel instantiation.  Returns true when the attribute
+// still has to be set for the CURRENT device (and records it); thread-safe.
+inline bool first_launch_on_device(unsigned long long* done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  const unsigned long long bit = 1ull << dev;
+  return (__atomic_fetch_or(done, bit, __ATOMIC_ACQ_REL) & bit) == 0;
+}
+
 inline int launch_status(const char* what) {
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) {

@@ -386,12 +386,11 @@ int launch_conv_bf3(const ConvArgs& a_in, hipStream_t st) {
   TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
   constexpr size_t lds_bytes = G::LDS_BYTES;
   static_assert(lds_bytes <= 80 * 1024, "conv(bf16x3): LDS per workgroup too large for two per CU");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_done = 0;      // one bit per device
+  if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_set = true;
   }
   const int nrb = (a.rows + TB - 1) / TB;
   dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 64));

@@ -946,12 +946,11 @@ int launch_conv(const ConvArgs& a_in, hipStream_t st) {
   constexpr size_t lds_bytes = G::LDS_FLOATS * sizeof(float);
   // two workgroups per CU must fit in the 160 KiB LDS
   static_assert(lds_bytes <= 80 * 1024, "conv: LDS per workgroup too large");
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_done = 0;      // one bit per device
+  if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_set = true;
   }
   const int nrb = (a.rows + TB - 1) / TB;
   dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 64));

@@ -24,7 +24,7 @@ __device__ __forceinline__ float wave_max(float v) {
   if (m >= M) return;                                     \
   const int ag = m / num_samp;                            \
   const float sc = scale[ag];                             \
-  if (sc == 0.f) return;
+  if (sc < 0.f) return;
 
 // ---- TargetPosLoss, guidance_loss.py:523-540 ------------------------------------------
 __global__ __launch_bounds__(256) void target_pos_kernel(const float* __restrict__ traj,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void map_collision_kernel(
   const int m = mt / T;
   const int ag = m / num_samp;
   const float sc = scale[ag];
-  if (sc == 0.f) return;
+  if (sc < 0.f) return;
   const float* p = traj + (size_t)mt * 6;
   const float px = p[0], py = p[1], yaw = p[3];
   const float el = extent[ag * 3], ew = extent[ag * 3 + 1];

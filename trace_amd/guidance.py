@@ -50,6 +50,35 @@ def verify_guidance_config_list(guidance_config_list):
     return any(len(g) > 0 for g in guidance_config_list)
 
 
+def choose_action_from_guidance(preds, obs_dict, guide_configs, guide_losses):
+    """Best-of-N sample per agent from the per-guide losses, the reference's public free function
+    (guidance_loss.py:15-41): ``guide_losses`` maps "<name>_scene_%03d_%02d" -> (B, N) with NaN outside the
+    guide's agents, in scene-major order; ``guide_configs`` is the per-scene list of configs (objects with
+    ``.name`` or the config dicts).  Unweighted nansum over a scene's guides; one argmin per scene when the
+    scene has an agent_collision / social_group guide, per agent otherwise; agents no guide covers keep
+    sample 0.  Stays on the device (the reference copies to the host every call).  The sampler's own path
+    (``GuidancePlan.choose_action``) works on the compact per-layer losses instead."""
+    pos = preds["positions"]
+    B, N = pos.shape[0], pos.shape[1]
+    act_idx = torch.zeros(B, dtype=torch.long, device=pos.device)
+    per_guide = [v for _, v in guide_losses.items()]
+    first = 0
+    for scene_cfgs in guide_configs:
+        mine = per_guide[first:first + len(scene_cfgs)]
+        first += len(scene_cfgs)
+        stack = torch.stack(mine, dim=2) if mine else pos.new_zeros(B, N, 0)
+        covered = ~torch.isnan(stack.sum(dim=(1, 2)))       # an empty guide list covers everybody (reference quirk)
+        if not bool(covered.any()):
+            continue
+        total = torch.nansum(stack[covered], dim=-1)        # (B', N)
+        names = [c["name"] if isinstance(c, dict) else c.name for c in scene_cfgs]
+        if any(n in SCENE_LEVEL for n in names):
+            act_idx[covered] = torch.argmin(total.sum(dim=0))
+        else:
+            act_idx[covered] = torch.argmin(total, dim=-1)
+    return act_idx
+
+
 class _Item:
     """One kernel-level objective over a set of agents (part of one guidance config)."""
     __slots__ = ("kind", "key", "mask", "tables", "layer")
@@ -155,19 +184,29 @@ class GuidancePlan:
         # pack items into layers: same kind/static key, disjoint masks
         self.layers = []
         for it in items:
+            # scene-coupled objectives: two configs of ONE scene never share a launch -- the pair kernel doubles
+            # a pair's gradient when both agents are guided by the SAME config, while the reference detaches the
+            # agents of any other config (guidance_loss.py:272-282)
+            claim = it.mask
+            if it.kind in SCENE_LEVEL:
+                claim = sid == int(sid[it.mask][0]) if bool(it.mask.any()) else it.mask
             for li, ly in enumerate(self.layers):
-                if ly["kind"] == it.kind and ly["key"] == it.key and not bool((ly["mask"] & it.mask).any()):
+                if ly["kind"] == it.kind and ly["key"] == it.key and not bool((ly["claim"] & claim).any()):
                     break
             else:
                 li = len(self.layers)
-                self.layers.append({"kind": it.kind, "key": it.key,
-                                    "mask": torch.zeros(B, dtype=torch.bool), "tables": {}})
+                self.layers.append({"kind": it.kind, "key": it.key, "mask": torch.zeros(B, dtype=torch.bool),
+                                    "claim": torch.zeros(B, dtype=torch.bool), "tables": {}})
                 ly = self.layers[li]
             it.layer = li
             ly["mask"] |= it.mask
+            ly["claim"] |= claim
             for k, v in it.tables.items():
                 if k not in ly["tables"]:
-                    ly["tables"][k] = torch.zeros((B,) + tuple(v.shape[1:]), dtype=v.dtype)
+                    # scale < 0 marks agents the layer does not cover; a covered agent of weight 0 keeps its
+                    # loss (the reference still evaluates and reports it, and selection uses it)
+                    fill = -1.0 if k == "scale" else 0
+                    ly["tables"][k] = torch.full((B,) + tuple(v.shape[1:]), fill, dtype=v.dtype)
                 ly["tables"][k][it.mask] = v
         # device tables
         f32 = lambda t: t.to(device=device, dtype=torch.float32).contiguous()
