@@ -34,34 +34,16 @@
 
 namespace trace {
 
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
-  unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-  return r;
-}
-
-// 8 fp32 values -> three bf16 planes (exact three-way split)
-__device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4v& h, u32x4v& m, u32x4v& l) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float a0 = v[2 * i], a1 = v[2 * i + 1];
-    const unsigned ph = cvt_pk_bf16(a0, a1);
-    const float r0 = a0 - __builtin_bit_cast(float, ph << 16);
-    const float r1 = a1 - __builtin_bit_cast(float, ph & 0xffff0000u);
-    const unsigned pm = cvt_pk_bf16(r0, r1);
-    const float s0 = r0 - __builtin_bit_cast(float, pm << 16);
-    const float s1 = r1 - __builtin_bit_cast(float, pm & 0xffff0000u);
-    h[i] = ph;
-    m[i] = pm;
-    l[i] = cvt_pk_bf16(s0, s1);
-  }
-}
-
-template <int L_OUT, int UP, int TAPS, int PADL, int TB>
+#ifndef TRACE_BF3_NW
+#define TRACE_BF3_NW 4            // waves per workgroup of the full-chip launches (small launches: launch_conv_bf3)
+#endif
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW>
 struct Bf3Geom {
+  static constexpr int NTH = NW * 64;                      // threads per workgroup
+  static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
+  // wave w owns column tile w & 3 and part w >> 2 of the row tiles: the NRT tiles are dealt to NW / 4 parts,
+  // the first NRT % NPART parts take one more
+  static constexpr int NPART = NW / 4;
   static constexpr int CH = 32;                            // channels per chunk = one MFMA k-slice per tap
   static constexpr int R = TB * L_OUT;
   static constexpr int NRT = R / 16;
@@ -81,7 +63,9 @@ struct Bf3Geom {
   static constexpr int PLANE = 4 * SUB;                    // bytes per plane
   static constexpr int NPOS = TB * L_IN;                   // data positions per chunk
   static constexpr int NU = NPOS * (CH / 8);               // staging units (position, channel octet)
-  static constexpr int NUT = (NU + 255) / 256;
+  static constexpr int NUT = (NU + NTH - 1) / NTH;
+  static constexpr int NACC = (NRT + NPART - 1) / NPART;       // accumulator tiles per wave (the larger parts)
+  static constexpr int NREM = NRT % NPART;                     // parts that have NACC tiles (0: all of them)
   // the output tile (conv_epilogue) + the 32-channel-group exchange area of conv_epilogue_fwd_rows
   static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float) + 2 * 4 * TB * sizeof(float);
   static constexpr size_t LDS_BYTES = (size_t)3 * PLANE > EPI_BYTES ? (size_t)3 * PLANE : EPI_BYTES;
@@ -92,17 +76,31 @@ struct Bf3Geom {
 #ifndef TRACE_BF3_WGS
 #define TRACE_BF3_WGS 2           // resident workgroups per CU the register budget is sized for
 #endif
-template <int L_OUT, int UP, int TAPS, int PADL, int TB>
-__global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB>;
-  constexpr int NRT = G::NRT, LP = G::LP, L_IN = G::L_IN, SUB = G::SUB, PLANE = G::PLANE;
-  constexpr int NUT = G::NUT, NU = G::NU, NPOS = G::NPOS, CH = G::CH;
+#ifndef TRACE_BF3_WGS_PLN
+#define TRACE_BF3_WGS_PLN 2       // ... when the input comes as pre-split planes (no staging registers)
+#endif
+// PLN: the input is staged from pre-split bf16 plane tensors (ConvArgs::inp / in2p) by LDS-DMA loads; otherwise
+// from the fp32 tensor through registers with the split in the kernel.
+// MINW = waves per SIMD the register budget is sized for (2: up to 256 VGPRs)
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int NW = TRACE_BF3_NW,
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4>
+__global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW>;
+  constexpr int LP = G::LP, L_IN = G::L_IN, SUB = G::SUB, PLANE = G::PLANE;
+  constexpr int NUT = G::NUT, NU = G::NU, NPOS = G::NPOS, CH = G::CH, NTH = G::NTH, NACC = G::NACC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   char* const ldsb = reinterpret_cast<char*>(lds);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  // wave -> (column tile, row tiles).  A workgroup's waves go to the SIMDs cyclically, so the waves of one
+  // column tile (w, w + 4, ...) share a SIMD and every SIMD carries the same MFMA load.
+  const int cwave = wave & 3;
+  const int rpart = wave >> 2;
+  constexpr int NREM = G::NREM;
+  const int nrtw = (NREM == 0 || rpart < NREM) ? NACC : NACC - 1;
+  const int rt0 = NREM == 0 ? rpart * NACC : (rpart < NREM ? rpart * NACC : NREM * NACC + (rpart - NREM) * (NACC - 1));
   // workgroup id -> (row block, column tile): see conv_gemm_kernel
   const int ncol = a.cout >> 6;
   const int bid = blockIdx.x;
@@ -120,81 +118,132 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
 #endif
 
   // ---- staging ------------------------------------------------------------------------------
+  const int nch1 = a.cin / CH;
+  const int nch = nch1 + a.cin2 / CH;
+  // (a) planes: wave w copies channel octet w of the chunk, three planes x NPIECE pieces of 64 cells (1 KiB,
+  // one LDS-DMA wave-instruction: lane -> consecutive 16-byte LDS cells, per-lane source address).  Cell s of a
+  // (plane, octet) array is position s % LP - PADL of trajectory s / LP; halo, zero-stuffing and padding cells
+  // read the 16 zero bytes of a.zero_cell, so the image needs no separate zero fill.
+  constexpr int SUBC = SUB / 16;
+  constexpr int NPIECE = (SUBC + 63) / 64;
+  int psrc[PLN ? NPIECE : 1];                  // (trajectory << 16 | input position) of the lane's cell, -1 = zeros
+  if constexpr (PLN) {
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int sc = 64 * j + lane;
+      const int tr = sc / LP;
+      const int ii = sc - tr * LP - PADL;
+      const bool ok = sc < G::S && ii >= 0 && (ii % UP) == 0 && (ii / UP) < L_IN && traj0 + tr < a.rows;
+      psrc[j] = ok ? (tr << 16) | (ii / UP) : -1;
+    }
+  }
+  auto stage_dma = [&](int ch) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+    const bool second = ch >= nch1;
+    const char* base = reinterpret_cast<const char*>(second ? a.in2p : a.inp);
+    const int noct = second ? a.in2p_noct : a.inp_noct;
+    const int oct = (second ? a.in2p_oct0 + (ch - nch1) * 4 : a.inp_oct0 + ch * 4) + cwave;
+    const size_t rowcells = (size_t)3 * noct * L_IN;             // cells per trajectory
+    const char* const zero = reinterpret_cast<const char*>(a.zero_cell);
+    const char* tb = base + ((size_t)traj0 * rowcells + (size_t)oct * L_IN) * 16;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int j = 0; j < NPIECE; ++j) {
+        const int ps = psrc[j];
+        const char* src = ps >= 0 ? tb + ((size_t)(ps >> 16) * rowcells + (size_t)(ps & 0xffff)) * 16 : zero;
+        char* dst = ldsb + pl * PLANE + cwave * SUB + j * 1024;      // wave-uniform
+        if ((SUBC % 64 == 0) || j + 1 < NPIECE || 64 * j + lane < SUBC)
+          __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+      }
+      tb += (size_t)noct * L_IN * 16;                               // next plane
+    }
+  };
+
+  // (b) fp32 tensor through registers
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
       0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in2 ? a.in2 : a.in), 0,
       a.in2 ? (unsigned)((size_t)a.rows * a.in2_tstride * sizeof(float)) : 0u, 0x00020000);
-  const int nch1 = a.cin / CH;
-  const int nch = nch1 + a.cin2 / CH;
-  // unit q = tid + 256 j: octet o = q / NPOS, position pp = q % NPOS (lanes run along positions)
-  unsigned spk[NUT];            // (trajectory in tile) << 20 | float offset inside the chunk
-  unsigned wofs[NUT];           // LDS byte offset of the unit inside a plane
+  constexpr int NUTR = PLN ? 1 : NUT;          // register-staging state only exists without planes
+  // unit q = tid + NTH j: octet o = q / NPOS, position pp = q % NPOS (lanes run along positions)
+  unsigned spk[NUTR];           // (trajectory in tile) << 20 | float offset inside the chunk
+  unsigned wofs[NUTR];          // LDS byte offset of the unit inside a plane
+  if constexpr (!PLN) {
 #pragma unroll
-  for (int j = 0; j < NUT; ++j) {
-    const int q = tid + 256 * j;
-    const int o = q / NPOS;
-    const int pp = q - o * NPOS;
-    const int tr = pp / L_IN;
-    const int i = pp - tr * L_IN;
-    spk[j] = ((unsigned)tr << 20) | (unsigned)(o * 8 * L_IN + i);
-    wofs[j] = (unsigned)((tr * LP + i * UP + PADL) * 16 + o * SUB);
+    for (int j = 0; j < NUT; ++j) {
+      const int q = tid + NTH * j;
+      const int o = q / NPOS;
+      const int pp = q - o * NPOS;
+      const int tr = pp / L_IN;
+      const int i = pp - tr * L_IN;
+      spk[j] = ((unsigned)tr << 20) | (unsigned)(o * 8 * L_IN + i);
+      wofs[j] = (unsigned)((tr * LP + i * UP + PADL) * 16 + o * SUB);
+    }
   }
-  float stg[NUT][8];
+  float stg[NUTR][8];
   // the 8 channel loads of unit j of chunk ch (cbase / descriptor choice are wave-uniform)
   auto stage_load_unit = [&](int ch, int j) {
-    const bool second = ch >= nch1;
-    const int tstride = second ? a.in2_tstride : a.in_tstride;
-    const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
-                      traj0 * tstride;
-    // units past NU (last pass) read a valid address and are never written to LDS; trajectories
-    // past `rows` fall outside the descriptor's range and read as zeros
-    const bool live = (NU % 256 == 0) || (tid + 256 * j < NU);
-    const unsigned off = live ? ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u : 0u;
+    if constexpr (!PLN) {
+      const bool second = ch >= nch1;
+      const int tstride = second ? a.in2_tstride : a.in_tstride;
+      const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
+                        traj0 * tstride;
+      // units past NU (last pass) read a valid address and are never written to LDS; trajectories
+      // past `rows` fall outside the descriptor's range and read as zeros
+      const bool live = (NU % NTH == 0) || (tid + NTH * j < NU);
+      const unsigned off = live ? ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u : 0u;
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
-      stg[j][jj] = second ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, jj * L_IN * 4, 0))
-                          : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, jj * L_IN * 4, 0));
+      for (int jj = 0; jj < 8; ++jj) {
+        stg[j][jj] = second ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, jj * L_IN * 4, 0))
+                            : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, off, jj * L_IN * 4, 0));
+      }
     }
   };
 #ifndef TRACE_BF3_SPLIT_IN_K
 #define TRACE_BF3_SPLIT_IN_K 0    // split the next chunk into bf16 planes between the MFMAs of the current one
 #endif
-  constexpr bool SPLITK = TRACE_BF3_SPLIT_IN_K && TAPS > 1;     // the 1x1 kernels have no MFMA shadow to hide it in
-  u32x4v sph[NUT], spm[NUT], spl[NUT];
-  auto split_unit = [&](int j) { split8_bf16(stg[j], sph[j], spm[j], spl[j]); };
+  constexpr bool SPLITK = TRACE_BF3_SPLIT_IN_K && TAPS > 1 && !PLN;     // the 1x1 kernels have no MFMA shadow to hide it in
+  u32x4v sph[NUTR], spm[NUTR], spl[NUTR];
+  auto split_unit = [&](int j) { if constexpr (!PLN) split8_bf16(stg[j], sph[j], spm[j], spl[j]); };
   // the bf16 planes of the staged chunk go to LDS from sph / spm / spl
   auto stage_write = [&]() {
+    if constexpr (!PLN) {
 #pragma unroll
-    for (int j = 0; j < NUT; ++j) {
-      if ((NU % 256 == 0) || (tid + 256 * j < NU)) {
-        char* p = ldsb + wofs[j];
-        *reinterpret_cast<u32x4v*>(p) = sph[j];
-        *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
-        *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = spl[j];
+      for (int j = 0; j < NUT; ++j) {
+        if ((NU % NTH == 0) || (tid + NTH * j < NU)) {
+          char* p = ldsb + wofs[j];
+          *reinterpret_cast<u32x4v*>(p) = sph[j];
+          *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
+          *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = spl[j];
+        }
       }
     }
   };
 
+  if constexpr (!PLN) {
 #pragma unroll
-  for (int j = 0; j < NUT; ++j) stage_load_unit(0, j);
-  // halo / zero-stuffing positions are written once; data positions are rewritten by every chunk
-  if constexpr (UP == 1 && TAPS == 1) {
-  } else if constexpr (UP == 1) {
-    constexpr int HALO = LP - L_IN;                      // PADL cells in front of the data, the rest behind
-    for (int i = tid; i < 12 * TB * HALO; i += 256) {    // (plane, octet) arrays x trajectories x halo cells
-      const int arr = i / (TB * HALO);
-      const int r0 = i - arr * (TB * HALO);
-      const int tr = r0 / HALO;
-      const int h = r0 - tr * HALO;
-      const int pos = tr * LP + (h < PADL ? h : L_IN + h);
-      *reinterpret_cast<u32x4v*>(ldsb + arr * SUB + pos * 16) = u32x4v{0u, 0u, 0u, 0u};
-    }
-  } else {
+    for (int j = 0; j < NUT; ++j) stage_load_unit(0, j);
+    // halo / zero-stuffing positions are written once; data positions are rewritten by every chunk
+    if constexpr (UP == 1 && TAPS == 1) {
+    } else if constexpr (UP == 1) {
+      constexpr int HALO = LP - L_IN;                      // PADL cells in front of the data, the rest behind
+      for (int i = tid; i < 12 * TB * HALO; i += NTH) {    // (plane, octet) arrays x trajectories x halo cells
+        const int arr = i / (TB * HALO);
+        const int r0 = i - arr * (TB * HALO);
+        const int tr = r0 / HALO;
+        const int h = r0 - tr * HALO;
+        const int pos = tr * LP + (h < PADL ? h : L_IN + h);
+        *reinterpret_cast<u32x4v*>(ldsb + arr * SUB + pos * 16) = u32x4v{0u, 0u, 0u, 0u};
+      }
+    } else {
 #pragma unroll 2
-    for (int i = tid; i < 3 * PLANE / 16; i += 256)
-      reinterpret_cast<u32x4v*>(ldsb)[i] = u32x4v{0u, 0u, 0u, 0u};
+      for (int i = tid; i < 3 * PLANE / 16; i += NTH)
+        reinterpret_cast<u32x4v*>(ldsb)[i] = u32x4v{0u, 0u, 0u, 0u};
+    }
   }
 
   // lane (MFMA row i = lane & 15, kq = lane >> 4) reads channels 8 kq .. 8 kq + 7 of the input position of
@@ -207,15 +256,15 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
   int tapoff[TAPS];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
-    tapoff[t] = rowoff0 + t * 16;
+    tapoff[t] = rowoff0 + t * 16 + rt0 * PPT * 16;
     asm volatile("" : "+v"(tapoff[t]));
   }
-  f32x4 acc[NRT];
+  f32x4 acc[NACC];
 #pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int rt = 0; rt < NACC; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wb) + ((size_t)(ct * 4 + wave) * a.nsl) * 192 + lane;
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wb) + ((size_t)(ct * 4 + cwave) * a.nsl) * 192 + lane;
 #ifndef TRACE_BF3_WPF
 #define TRACE_BF3_WPF 2           // weight slices in flight ahead of the one being multiplied
 #endif
@@ -234,13 +283,13 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
   // one chunk's MFMAs over taps [T0, T1); the next chunk's activations (chunk `next`, -1 = none) are
   // requested one staging unit at a time between row tiles, after the slice's weight loads, so that
   // neither the issue of 32 loads in a row nor a vmcnt wait for weights stalls on them
-  auto chunk_mma = [&](auto t0c, auto t1c, const int next) {
-    constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value;
-    constexpr int NT = (T1 - T0) * NRT;
+  auto chunk_mma = [&](auto t0c, auto t1c, auto nrc, const int next) {
+    constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NR = decltype(nrc)::value;
+    constexpr int NT = (T1 - T0) * NR;
     constexpr int NST = TAPS == 1 ? (TRACE_BF3_NST < 3 ? TRACE_BF3_NST : 3) : TRACE_BF3_NST, DIST = NST - 1;   // A register stages / prefetch distance in tiles
     bf16x8 av[NST][3];
     auto load_a = [&](int n, int stage) {
-      const int tap = T0 + n / NRT, rt = n % NRT;
+      const int tap = T0 + n / NR, rt = n % NR;
       const char* p = ldsb + tapoff[tap] + rt * PPT * 16;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) av[stage][pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
@@ -250,7 +299,7 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
     bf16x8 b[3];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      if (n % NRT == 0) {
+      if (n % NR == 0) {
         if constexpr (TRACE_BF3_WPF >= 2) {
 #pragma unroll
           for (int p = 0; p < 3; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
@@ -276,7 +325,7 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
 #define TRACE_BF3_LOAD_SPREAD 0   // row tiles between the global loads of two staging units of the next chunk (0: all at once)
 #endif
       if constexpr (TRACE_BF3_LOAD_SPREAD == 0) {
-        if (n == 1 && (SPLITK || next >= 0)) {
+        if (!PLN && n == 1 && (SPLITK || next >= 0)) {
 #pragma unroll
           for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
         }
@@ -295,7 +344,7 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
         constexpr int FIRST = NT - NUT > 2 ? NT - NUT : 2;
         if (n >= FIRST && n - FIRST < NUT) split_unit(n - FIRST);
       }
-      const int s = n % NST, rt = n % NRT;
+      const int s = n % NST, rt = n % NR;
       f32x4 c = acc[rt];
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][2], b[0], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[2], c, 0, 0, 0);
@@ -320,20 +369,35 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
   TRACE_STAMP(14);
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();            // previous chunk fully consumed (and zero fill done)
-    if (!SPLITK || ch == 0) {
+    if constexpr (PLN) {
+      stage_dma(ch);            // the barrier below waits for it (vmcnt(0) ahead of the s_barrier)
+    } else {
+      if (!SPLITK || ch == 0) {
 #pragma unroll
-      for (int j = 0; j < NUT; ++j) split_unit(j);
+        for (int j = 0; j < NUT; ++j) split_unit(j);
+      }
+      stage_write();
     }
-    stage_write();
     if (ch == 0) TRACE_STAMP(15);
     __syncthreads();
     if (ch == 0) TRACE_STAMP(1);
     // with the in-K split the body is branch-free: the last chunk re-stages itself (never written)
-    const int next = ch + 1 < nch ? ch + 1 : (SPLITK ? ch : -1);
-    if (ch < nch1)
-      chunk_mma(std::integral_constant<int, 0>{}, std::integral_constant<int, TAPS>{}, next);
-    else
-      chunk_mma(std::integral_constant<int, PADL>{}, std::integral_constant<int, PADL + 1>{}, next);
+    const int next = PLN ? -1 : (ch + 1 < nch ? ch + 1 : (SPLITK ? ch : -1));
+    using IC0 = std::integral_constant<int, 0>;
+    using ICT = std::integral_constant<int, TAPS>;
+    using ICP = std::integral_constant<int, PADL>;
+    using ICP1 = std::integral_constant<int, PADL + 1>;
+    {
+      using NRC = std::integral_constant<int, NACC>;
+      using NRC2 = std::integral_constant<int, NREM != 0 ? NACC - 1 : NACC>;
+      if (NREM == 0 || rpart < NREM) {                     // wave-uniform
+        if (ch < nch1) chunk_mma(IC0{}, ICT{}, NRC{}, next);
+        else chunk_mma(ICP{}, ICP1{}, NRC{}, next);
+      } else if constexpr (NREM != 0) {
+        if (ch < nch1) chunk_mma(IC0{}, ICT{}, NRC2{}, next);
+        else chunk_mma(ICP{}, ICP1{}, NRC2{}, next);
+      }
+    }
     // stamps 2, 3: first two chunks; 4, 5: last two (scripts/stamps.py takes the last as the K end)
     if (ch < 2) TRACE_STAMP(2 + ch);
     else if (ch == nch - 2) TRACE_STAMP(4);
@@ -344,17 +408,24 @@ __global__ __launch_bounds__(256, TRACE_BF3_WGS) void conv_bf3_kernel(ConvArgs a
 #ifndef TRACE_BF3_EPI_REGS
 #define TRACE_BF3_EPI_REGS 0      // forward GroupNorm / Mish on the accumulators (conv_epilogue_fwd_rows)
 #endif
-  if (TRACE_BF3_EPI_REGS && !a.gnb)
-    conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0);
-  else
-    conv_epilogue<L_OUT, TB, 1>(a, acc, lds, traj0, co0);
+  if constexpr (TRACE_BF3_EPI_REGS && NW == 4) {
+    if (!a.gnb) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0); return; }
+  }
+  conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw);
 }
 
-template <int L_OUT, int UP, int TAPS, int PADL, int TB>
-int launch_conv_bf3(const ConvArgs& a_in, hipStream_t st) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB>;
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int NW = TRACE_BF3_NW,
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4>
+int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW>;
   ConvArgs a = a_in;
   if (a.rows <= 0) return TRACE_OK;
+  TRACE_REQUIRE(!PLN || (a.inp && a.zero_cell && a.inp_noct > 0 && (a.cin2 == 0 || (a.in2p && a.in2p_noct > 0)) &&
+                         (reinterpret_cast<uintptr_t>(a.inp) & 15) == 0 && TB * G::LP < 65536),
+                "conv(bf16x3, planes): plane tensors of the input(s) missing or misaligned");
+  TRACE_REQUIRE((!a.outp || (a.outp_noct > 0 && (reinterpret_cast<uintptr_t>(a.outp) & 15) == 0)) &&
+                    (!a.rawp || (a.rawp_noct > 0 && (reinterpret_cast<uintptr_t>(a.rawp) & 15) == 0)),
+                "conv(bf16x3): bad output plane tensor");
   TRACE_REQUIRE(a.wb && a.cout % 64 == 0 && a.cin % 32 == 0 && a.cin2 % 32 == 0 &&
                     a.nsl == TAPS * a.cin / 32 + a.cin2 / 32,
                 "conv(bf16x3): bad channel geometry cin=%d cin2=%d cout=%d nsl=%d", a.cin, a.cin2, a.cout,
@@ -389,7 +460,7 @@ int launch_conv_bf3(const ConvArgs& a_in, hipStream_t st) {
   static unsigned long long attr_done = 0;      // one bit per device
   if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB>),
+        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, NW, MINW>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
   }
   const int nrb = (a.rows + TB - 1) / TB;
@@ -399,9 +470,26 @@ int launch_conv_bf3(const ConvArgs& a_in, hipStream_t st) {
 #endif
   const bool prof = prof_active();
   if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB>), grid, dim3(256), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, NW, MINW>), grid, dim3(G::NTH), lds_bytes, st, a);
   if (prof) prof_post(st, 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT);
   return launch_status("conv_bf3_kernel");
+}
+
+// planes staging when the caller has the input's plane tensors (and, for a second K source, that one's too).
+// Small launches -- at most one workgroup per CU, so a layer lasts as long as ONE workgroup (the reference's
+// own CPU-runnable case, 320 trajectories: 80 workgroups) -- run 16 waves per workgroup: each wave then owns a
+// quarter of the row tiles of its column tile (4 / 3 / 3 / 3) and the K loop of the workgroup is a quarter as long.
+#ifndef TRACE_BF3_SMALL_NW
+#define TRACE_BF3_SMALL_NW 16
+#endif
+template <int L_OUT, int UP, int TAPS, int PADL, int TB>
+int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
+  if (a.inp && (a.cin2 == 0 || a.in2p)) return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, true>(a, st);
+  const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
+  static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
+  if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max)
+    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
+  return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false>(a, st);
 }
 
 }  // namespace trace

@@ -85,7 +85,81 @@ struct ConvArgs {
   int nsl;             // k-slices of 32 = taps * cin_b / 32 + cin2 / 32
   int cin_b;           // input channels of the split-bf16 stream (cin_real rounded up to 32, zero weights)
   unsigned long long* dbg;   // diagnostic builds only (TRACE_CONV_STAMPS): 16 time stamps per workgroup
+  // Pre-split bf16 PLANE tensors (the conv_bf3_kernel operand format): an fp32
+  // activation x = h + m + l exactly, the three bf16 planes stored as 16-byte cells of 8 consecutive
+  // channels of one position, cell index ((row * 3 + plane) * noct + oct) * L + pos (noct = channels / 8 of
+  // the underlying buffer).  A producer's epilogue writes them next to its fp32 output; a consumer's K loop
+  // copies them global -> LDS with LDS-DMA loads, no registers and no conversion work in between.
+  const void* inp;           // planes of `in` (null: stage from the fp32 tensor)
+  int inp_noct, inp_oct0;
+  const void* in2p;          // planes of `in2`
+  int in2p_noct, in2p_oct0;
+  void* outp;                // planes of `out` to write, or null
+  int outp_noct, outp_oct0;
+  void* rawp;                // planes of `out_raw` to write (GroupNorm-backward epilogue), or null
+  int rawp_noct, rawp_oct0;
+  const void* zero_cell;     // 16 zero bytes in device memory: the source of halo / zero-stuffing cells
 };
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+
+// 8 fp32 values -> three bf16 planes (exact three-way split)
+__device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4v& h, u32x4v& m, u32x4v& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = v[2 * i], a1 = v[2 * i + 1];
+    const unsigned ph = cvt_pk_bf16(a0, a1);
+    const float r0 = a0 - __builtin_bit_cast(float, ph << 16);
+    const float r1 = a1 - __builtin_bit_cast(float, ph & 0xffff0000u);
+    const unsigned pm = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, pm << 16);
+    const float s1 = r1 - __builtin_bit_cast(float, pm & 0xffff0000u);
+    h[i] = ph;
+    m[i] = pm;
+    l[i] = cvt_pk_bf16(s0, s1);
+  }
+}
+
+// The finished 64-channel output tile in LDS ([trajectory][channel][position] fp32) -> plane cells in HBM.
+// One unit = (trajectory, channel octet, position): 8 strided LDS reads (lanes run along positions, so a
+// read is a run of consecutive words), one exact split, three 16-byte stores to consecutive cells.
+template <int L_OUT, int TB, int NTH>
+__device__ __forceinline__ void write_planes(const float* lds, void* planes, const int noct, const int oct_base,
+                                             const int traj0, const int rows) {
+  constexpr int NUNITS = TB * 8 * L_OUT;
+  constexpr int NK = (NUNITS + NTH - 1) / NTH;
+  char* const base = reinterpret_cast<char*>(planes);
+#pragma unroll 1
+  for (int k = 0; k < NK; ++k) {
+    const int u = (int)threadIdx.x + NTH * k;
+    if (u >= NUNITS) break;
+    const int tr = u / (8 * L_OUT);
+    const int r = u - tr * (8 * L_OUT);
+    const int o = r / L_OUT;
+    const int pos = r - o * L_OUT;
+    const float* src = lds + (tr * 64 + o * 8) * L_OUT + pos;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[j * L_OUT];
+    u32x4v h, m, l;
+    split8_bf16(v, h, m, l);
+    const int row = traj0 + tr;
+    if (row < rows) {
+      const size_t pstride = (size_t)noct * L_OUT * 16;                          // bytes between planes
+      char* dst = base + (((size_t)row * 3 * noct + (oct_base + o)) * L_OUT + pos) * 16;
+      *reinterpret_cast<u32x4v*>(dst) = h;
+      *reinterpret_cast<u32x4v*>(dst + pstride) = m;
+      *reinterpret_cast<u32x4v*>(dst + 2 * pstride) = l;
+    }
+  }
+}
 
 #ifdef TRACE_CONV_STAMPS
 #define TRACE_STAMP(i)                                                                \
@@ -162,26 +236,38 @@ __device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
 //   0  rows in natural order:  r = 16 rt + i = trajectory * L_OUT + position        (conv_gemm_kernel)
 //   1  trajectory-major tiles: tile rt holds positions PPT rt .. PPT rt + PPT - 1 (PPT = L_OUT / 13) of
 //      all TB trajectories, i = trajectory * PPT + (position - PPT rt)               (conv_bf3_kernel)
-template <int L_OUT, int TB, int ROWMAP = 0>
-__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB * L_OUT / 16], float* lds,
-                                              const int traj0, const int co0) {
+// NW = waves per workgroup.  With NW = 8 (conv_bf3_kernel) wave w owns column tile w & 3 and the row tiles
+// rt0 .. rt0 + nrtw - 1 (the 13 row tiles split 7 / 6 between the two waves of a column tile): NACC
+// accumulator tiles, of which the first nrtw are live.
+template <int L_OUT, int TB, int ROWMAP = 0, int NW = 4, int NACC = TB * L_OUT / 16>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NACC], float* lds,
+                                              const int traj0, const int co0, const int rt0 = 0,
+                                              const int nrtw = NACC) {
   constexpr int R = TB * L_OUT, NRT = R / 16;
   constexpr int TILE = 64 * L_OUT;
-  constexpr int NQ = R * 64 / 4 / 256;
+  constexpr int NTH = NW * 64;                       // threads of the workgroup
+  constexpr int NF4 = R * 64 / 4;                    // 16-byte cells of the output tile
+  constexpr int NQ = (NF4 + NTH - 1) / NTH;
+  constexpr bool QTAIL = NF4 % NTH != 0;             // the last flat pass is partial
+  static_assert(NW == 4 || ROWMAP == 1, "8-wave workgroups use the trajectory-major tiles");
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const int cwave = wave & 3;                        // column tile of the wave
   const bool has_tab = a.gn || a.pc;
+  auto flat_live = [&](int k) -> bool { return !QTAIL || (tid + NTH * k) < NF4; };
   auto flat_off = [&](int k, int tstride, int coff, int& rem_out) -> unsigned {
-    const int f = (tid + 256 * k) * 4;
+    const int f = (tid + NTH * k) * 4;
     const int tr = f / TILE;
     const int rem = f - tr * TILE;
     rem_out = rem;
     const int tg = traj0 + tr;
-    // unsigned 32-bit byte offset: the launcher guarantees rows * tstride * 4 < 4 GiB
-    return tg < a.rows ? ((unsigned)tg * (unsigned)tstride + (unsigned)((coff + co0) * L_OUT + rem)) * 4u
-                       : 0xffffffffu;
+    // unsigned 32-bit byte offset: the launcher guarantees rows * tstride * 4 < 4 GiB; cells past the tile
+    // (partial last pass) and trajectories past `rows` fall outside every descriptor's range
+    return (tg < a.rows && flat_live(k)) ? ((unsigned)tg * (unsigned)tstride + (unsigned)((coff + co0) * L_OUT + rem)) * 4u
+                                         : 0xffffffffu;
   };
+  auto lds_cell = [&](int k) -> float* { return lds + (flat_live(k) ? (tid + NTH * k) * 4 : 0); };
   f32x4 rv[NQ];
   if (a.res) {
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
@@ -212,17 +298,19 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
   __syncthreads();
   {
     const int col = lane & 15, q = lane >> 4;
-    const int co_l = wave * 16 + col;
+    const int co_l = cwave * 16 + col;
     const float bv = a.bias ? a.bias[co0 + co_l] : 0.f;
     float* tcol = lds + co_l * L_OUT;
     int tr = 0, l = q * 4;                      // row r = rt*16 + q*4 + reg = tr*L_OUT + l
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
+    for (int ri = 0; ri < NACC; ++ri) {
+      if (ri >= nrtw) break;
+      const int rt = rt0 + ri;
       if constexpr (ROWMAP == 1) {
         constexpr int PPT = L_OUT / NRT;
         static_assert(PPT * NRT == L_OUT && PPT * TB == 16 && (PPT == 1 || PPT == 2 || PPT == 4),
                       "trajectory-major tiles need L_OUT = 13 PPT and TB = 16 / PPT");
-        f32x4 v = acc[rt];
+        f32x4 v = acc[ri];
         v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv;
         if constexpr (PPT == 4) {               // lane group q = trajectory, registers = 4 positions
           *reinterpret_cast<f32x4*>(tcol + q * TILE + 4 * rt) = v;
@@ -234,7 +322,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
           for (int reg = 0; reg < 4; ++reg) tcol[(4 * q + reg) * TILE + rt] = v[reg];
         }
       } else if constexpr (L_OUT % 4 == 0) {    // a quad of rows never straddles two trajectories
-        f32x4 v = acc[rt];
+        f32x4 v = acc[ri];
         v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv;
         *reinterpret_cast<f32x4*>(tcol + tr * TILE + l) = v;
       } else {
@@ -242,7 +330,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
         for (int reg = 0; reg < 4; ++reg) {
           int ll = l + reg, t2 = tr;
           if (ll >= L_OUT) { ll -= L_OUT; ++t2; }
-          tcol[t2 * TILE + ll] = acc[rt][reg] + bv;
+          tcol[t2 * TILE + ll] = acc[ri][reg] + bv;
         }
       }
       l += 16;
@@ -263,21 +351,33 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
         a.out_raw ? (unsigned)((size_t)a.rows * a.raw_tstride * sizeof(float)) : 0u, 0x00020000);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
-      const int f = (tid + 256 * k) * 4;
-      f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+      float* cell = lds_cell(k);
+      f32x4 y = *reinterpret_cast<const f32x4*>(cell);
       y += rv[k];
       if (a.out_raw) {
         int rem;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rw,
                                                flat_off(k, a.raw_tstride, a.raw_coff, rem), 0, 0);
       }
-      *reinterpret_cast<f32x4*>(lds + f) = y;
+      if (flat_live(k)) *reinterpret_cast<f32x4*>(cell) = y;
     }
-    if (!normed) { TRACE_STAMP(11); return; }  // uniform per workgroup
+    if (!normed) {                             // uniform per workgroup
+      if (a.rawp) {
+        __syncthreads();
+        write_planes<L_OUT, TB, NTH>(lds, a.rawp, a.rawp_noct, a.rawp_oct0 + (co0 >> 3), traj0, a.rows);
+      }
+      TRACE_STAMP(11);
+      return;
+    }
     __syncthreads();
-    // G2 (rows): thread = one (trajectory, channel) row per pass, lanes = channels
-    {
-      constexpr int NP = TB / 4;
+    if (a.rawp) {                              // the raw gradient's planes, before the rows are normalised in place
+      write_planes<L_OUT, TB, NTH>(lds, a.rawp, a.rawp_noct, a.rawp_oct0 + (co0 >> 3), traj0, a.rows);
+      __syncthreads();
+    }
+    // G2 (rows): thread = one (trajectory, channel) row per pass, lanes = channels; with more waves than
+    // trajectories (L = 52 on 8 waves) the upper waves have no row
+    if (TB >= NW || wave < TB) {
+      constexpr int NP = (TB + NW - 1) / NW;
       const int c = lane, co = co0 + c;
       const int cg = a.gb_cg, cgs = __builtin_ctz(cg);
       const float gam = a.gb_gamma[co], bet = a.gb_beta[co];
@@ -285,7 +385,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
       float gz[NP][L_OUT], xh[NP][L_OUT], s1[NP], s2[NP], rs[NP];
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        const int tr = wave + 4 * j;
+        const int tr = wave + NW * j;
         const int tg = min(traj0 + tr, a.rows - 1);
         const float* row = lds + (tr * 64 + c) * L_OUT;
         const float* yrow = a.gb_y + ((size_t)tg * a.gb_c + co) * L_OUT;
@@ -330,7 +430,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
       group_sum<NP>(s2, cg);
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
+        float* row = lds + ((wave + NW * j) * 64 + c) * L_OUT;
         const float m1 = s1[j] * inv_n, m2 = s2[j] * inv_n, rstd = rs[j];
 #pragma unroll
         for (int i = 0; i < L_OUT; ++i) gz[j][i] = rstd * (gz[j][i] - m1 - xh[j][i] * m2);
@@ -355,12 +455,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
         a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
-      const int f = (tid + 256 * k) * 4;
-      const f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
       int rem;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro,
                                              flat_off(k, a.out_tstride, a.out_coff, rem), 0, 0);
     }
+    if (a.outp)                                // the tile still holds d/dy
+      write_planes<L_OUT, TB, NTH>(lds, a.outp, a.outp_noct, a.outp_oct0 + (co0 >> 3), traj0, a.rows);
     TRACE_STAMP(11);
     return;
   }
@@ -372,8 +473,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
         a.ysave, 0, (unsigned)((size_t)a.rows * a.cout * L_OUT * sizeof(float)), 0x00020000);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
-      const int f = (tid + 256 * k) * 4;
-      const f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+      const f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
       int rem2;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ry,
                                              flat_off(k, a.cout * L_OUT, 0, rem2), 0, 0);
@@ -386,8 +486,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
   // keeps its rows in registers, normalises / activates / adds the condition there and writes the
   // finished rows back into the tile: no parameter table in LDS, so the tile alone (R x 64 floats =
   // 52 KB) is the epilogue's footprint and three workgroups fit a CU.
-  if (has_tab) {
-    constexpr int NP = TB / 4;
+  if (has_tab && (TB >= NW || wave < TB)) {
+    constexpr int NP = (TB + NW - 1) / NW;
     const int c = lane, co = co0 + c;
     const float gam = a.gn ? a.gamma[co] : 1.f;
     const float bet = a.gn ? a.beta[co] : 0.f;
@@ -397,11 +497,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
     float v[NP][L_OUT];
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      const int tg = min(traj0 + wave + 4 * j, a.rows - 1);
+      const int tg = min(traj0 + wave + NW * j, a.rows - 1);
       add[j] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
       rmean[j] = 0.f;
       m2[j] = 0.f;
-      const float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
+      const float* row = lds + ((wave + NW * j) * 64 + c) * L_OUT;
       if constexpr (L_OUT % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < L_OUT / 4; ++i) {
@@ -457,7 +557,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
       TRACE_STAMP(7);
 #pragma unroll
       for (int j = 0; j < NP; ++j) {
-        const int tr = wave + 4 * j;
+        const int tr = wave + NW * j;
         const float mean = gs[j];
         const float var = gv[j] / (float)(cg * L_OUT);
         const float rstd = 1.f / sqrtf(var + 1e-5f);
@@ -477,7 +577,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
     TRACE_STAMP(8);
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
-      float* row = lds + ((wave + 4 * j) * 64 + c) * L_OUT;
+      float* row = lds + ((wave + NW * j) * 64 + c) * L_OUT;
 #pragma unroll
       for (int i = 0; i < L_OUT; ++i) {
         float z = fmaf(v[j][i], scale[j], shift[j]);
@@ -496,8 +596,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
         for (int i = 0; i < L_OUT; ++i) row[i] = v[j][i];
       }
     }
-    __syncthreads();
   }
+  if (has_tab) __syncthreads();
   TRACE_STAMP(9);
 
   // E2: flat pass -- + residual(s), store; 4 consecutive outputs per access
@@ -505,12 +605,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[TB
       a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
-    const int f = (tid + 256 * k) * 4;
-    f32x4 y = *reinterpret_cast<const f32x4*>(lds + f);
+    f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
     int rem;
     const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
     y += rv[k];
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
+    if (a.outp && flat_live(k)) *reinterpret_cast<f32x4*>(lds_cell(k)) = y;      // the finished value, for the planes
+  }
+  if (a.outp) {
+    __syncthreads();
+    write_planes<L_OUT, TB, NTH>(lds, a.outp, a.outp_noct, a.outp_oct0 + (co0 >> 3), traj0, a.rows);
   }
   TRACE_STAMP(11);
 }

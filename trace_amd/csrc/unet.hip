@@ -271,11 +271,22 @@ struct trace_unet {
   // buffer plan (floats per row)
   std::vector<int> buf_floats;
   std::vector<char> buf_save_only;
+  std::vector<int> buf_twin;      // id of the buffer holding the pre-split bf16 planes of this one, or -1
+  void* zero_cell = nullptr;      // 16 zero bytes (halo source of the plane staging)
 
-  int new_buf(int floats, bool save_only) {
+  // planes: the activation is a conv input -> a twin buffer of 3 bf16 planes (6 bytes per element)
+  int new_buf(int floats, bool save_only, bool planes = false) {
     buf_floats.push_back(floats);
     buf_save_only.push_back(save_only ? 1 : 0);
-    return (int)buf_floats.size() - 1;
+    buf_twin.push_back(-1);
+    const int id = (int)buf_floats.size() - 1;
+    if (planes) {
+      buf_floats.push_back(floats + floats / 2);
+      buf_save_only.push_back(save_only ? 1 : 0);
+      buf_twin.push_back(-1);
+      buf_twin[id] = id + 1;
+    }
+    return id;
   }
   // ids
   std::vector<int> b_h1, b_out, b_res, b_y1, b_y2, b_s1, b_s2;
@@ -655,17 +666,22 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
   // ---- buffer plan -------------------------------------------------------------------
   const int H = cfg->horizon;
   const int d0 = cfg->dims[0], d1 = cfg->dims[1], d2 = cfg->dims[2];
-  u->b_cat1 = u->new_buf(2 * d1 * (H / 2), false);
-  u->b_cat2 = u->new_buf(2 * d2 * (H / 4), false);
-  u->b_ds[0] = u->new_buf(d0 * (H / 2), false);
-  u->b_ds[1] = u->new_buf(d1 * (H / 4), false);
-  u->b_up1 = u->new_buf(d0 * H, false);
+  // TRACE_BF3_PLANES=1: activations are ALSO kept as pre-split bf16 plane tensors and the convs stage them by
+  // LDS-DMA.  Measured and left off: 3283 against 3680 trajectories/s -- the split VALU
+  // work it removes is not what bounds the 256-channel layers (338 vs 337 us), while the 2.5x write traffic and the
+  // un-overlapped DMA latency cost the 64 / 128-channel and 1x1 layers 11 - 100 %.
+  const bool planes = getenv("TRACE_BF3_PLANES") && getenv("TRACE_BF3_PLANES")[0] == '1';
+  u->b_cat1 = u->new_buf(2 * d1 * (H / 2), false, planes);
+  u->b_cat2 = u->new_buf(2 * d2 * (H / 4), false, planes);
+  u->b_ds[0] = u->new_buf(d0 * (H / 2), false, planes);
+  u->b_ds[1] = u->new_buf(d1 * (H / 4), false, planes);
+  u->b_up1 = u->new_buf(d0 * H, false, planes);
   u->b_f = u->new_buf(d0 * H, false);
   u->b_yf = u->new_buf(d0 * H, true);
   u->b_sf = u->new_buf(16, true);
   for (auto& b : u->blocks) {
-    u->b_h1.push_back(u->new_buf(b.cout * b.L, false));
-    u->b_out.push_back(u->new_buf(b.cout * b.L, false));
+    u->b_h1.push_back(u->new_buf(b.cout * b.L, false, planes));
+    u->b_out.push_back(u->new_buf(b.cout * b.L, false, planes));
     u->b_res.push_back(b.has_res ? u->new_buf(b.cout * b.L, false) : -1);
     u->b_y1.push_back(u->new_buf(b.cout * b.L, true));
     u->b_y2.push_back(u->new_buf(b.cout * b.L, true));
@@ -675,12 +691,22 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
   int gmax = d0 * H;
   if (d1 * (H / 2) > gmax) gmax = d1 * (H / 2);
   if (d2 * (H / 4) > gmax) gmax = d2 * (H / 4);
-  u->b_T1 = u->new_buf(gmax, true);
-  u->b_T2 = u->new_buf(gmax, true);
-  u->b_G0 = u->new_buf(gmax, true);
-  u->b_G1 = u->new_buf(gmax, true);
-  u->b_dcat1 = u->new_buf(2 * d1 * (H / 2), true);
-  u->b_dcat2 = u->new_buf(2 * d2 * (H / 4), true);
+  u->b_T1 = u->new_buf(gmax, true, planes);
+  u->b_T2 = u->new_buf(gmax, true, planes);
+  u->b_G0 = u->new_buf(gmax, true, planes);
+  u->b_G1 = u->new_buf(gmax, true, planes);
+  u->b_dcat1 = u->new_buf(2 * d1 * (H / 2), true, planes);
+  u->b_dcat2 = u->new_buf(2 * d2 * (H / 4), true, planes);
+  {
+    void* z = nullptr;
+    if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) {
+      set_error("trace_unet_create: cannot allocate the zero cell");
+      trace_unet_destroy(u);
+      return TRACE_EHIP;
+    }
+    u->allocs.push_back(z);
+    u->zero_cell = z;
+  }
   *out = u;
   return TRACE_OK;
 }
@@ -721,8 +747,11 @@ Layout make_layout(const trace_unet* u, int rows, int save) {
 
 enum ConvKind { K_CONV5, K_CONV1, K_DOWN_F, K_UP_F, K_DOWN_B, K_UP_B };
 
+thread_local const void* t_zero_cell = nullptr;     // set by trace_unet_forward / _backward_input
+
 int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
+  a.zero_cell = t_zero_cell;
   // zero-stuffed (transposed) convolutions multiply half of their taps by structural zeros
   if (kind == K_UP_F || kind == K_DOWN_B) a.alg_macs_per_pos *= 0.5;
   const int ch = a.chunk;
@@ -805,7 +834,10 @@ struct View {
   int ctot;
   int coff;
   int L;
+  void* pl = nullptr;     // pre-split bf16 planes of the same (ctot, L) tensor, or null
   int tstride() const { return ctot * L; }
+  View sub(int c0) const { return View{p, ctot, coff + c0, L, pl}; }
+  View no_planes() const { return View{p, ctot, coff, L, nullptr}; }
 };
 
 ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const View& out,
@@ -829,6 +861,16 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.wb = w.wb;
   a.nsl = w.nsl;
   a.cin_b = w.cin_b;
+  if (in.pl && in.coff % 8 == 0 && in.ctot % 8 == 0) {
+    a.inp = in.pl;
+    a.inp_noct = in.ctot / 8;
+    a.inp_oct0 = in.coff / 8;
+  }
+  if (out.pl && out.coff % 8 == 0 && out.ctot % 8 == 0) {
+    a.outp = out.pl;
+    a.outp_noct = out.ctot / 8;
+    a.outp_oct0 = out.coff / 8;
+  }
   return a;
 }
 
@@ -836,6 +878,11 @@ void set_in2(ConvArgs& a, const View& v) {
   a.in2 = v.p;
   a.in2_tstride = v.tstride();
   a.in2_coff = v.coff;
+  if (v.pl && v.coff % 8 == 0 && v.ctot % 8 == 0) {
+    a.in2p = v.pl;
+    a.in2p_noct = v.ctot / 8;
+    a.in2p_oct0 = v.coff / 8;
+  }
 }
 
 // GroupNorm + Mish backward fused into a dgrad epilogue: `dy` receives d/dy of the layer whose
@@ -850,16 +897,28 @@ void set_gnb(ConvArgs& a, const float* y, const float* stats, const float* gamma
   a.gb_beta = beta;
   a.gb_cg = C / 8;
   a.gb_c = C;
+  a.rawp = nullptr;
   if (raw) {
     a.out_raw = raw->p;
     a.raw_tstride = raw->tstride();
     a.raw_coff = raw->coff;
+    if (raw->pl && raw->coff % 8 == 0 && raw->ctot % 8 == 0) {
+      a.rawp = raw->pl;
+      a.rawp_noct = raw->ctot / 8;
+      a.rawp_oct0 = raw->coff / 8;
+    }
   } else {
     a.out_raw = nullptr;
   }
   a.out = dy.p;
   a.out_tstride = dy.tstride();
   a.out_coff = dy.coff;
+  a.outp = nullptr;
+  if (dy.pl && dy.coff % 8 == 0 && dy.ctot % 8 == 0) {
+    a.outp = dy.pl;
+    a.outp_noct = dy.ctot / 8;
+    a.outp_oct0 = dy.coff / 8;
+  }
 }
 
 void set_res(ConvArgs& a, const View& r) {
@@ -928,16 +987,21 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in, const float*
   const float* pt = u->step_table + (size_t)step * u->width;
 
   // views of each block's input / output (skip concatenation is done by writing in place)
-  auto whole = [&](int id, int C, int L) { return View{buf(id), C, 0, L}; };
+  t_zero_cell = u->zero_cell;
+  // a buffer with its plane twin (the twin is written by the producing conv's epilogue)
+  auto whole = [&](int id, int C, int L) {
+    const int tw = id >= 0 ? u->buf_twin[id] : -1;
+    return View{buf(id), C, 0, L, tw >= 0 ? (void*)buf(tw) : nullptr};
+  };
   std::vector<View> bin(u->nblocks), bout(u->nblocks);
   const int d0 = c.dims[0], d1 = c.dims[1], d2 = c.dims[2];
-  View cat1{buf(u->b_cat1), 2 * d1, 0, H / 2}, cat2{buf(u->b_cat2), 2 * d2, 0, H / 4};
+  View cat1 = whole(u->b_cat1, 2 * d1, H / 2), cat2 = whole(u->b_cat2, 2 * d2, H / 4);
   // block order: d0.0 d0.1 d1.0 d1.1 d2.0 d2.1 mid1 mid2 u0.0 u0.1 u1.0 u1.1
   bin[0] = View{const_cast<float*>(x_in), u->cin_pad, 0, H};
   for (int i = 0; i < u->nblocks; ++i) bout[i] = whole(u->b_out[i], u->blocks[i].cout, u->blocks[i].L);
-  bout[3] = View{cat1.p, cat1.ctot, d1, cat1.L};   // d1.1 -> skip half of cat1
-  bout[5] = View{cat2.p, cat2.ctot, d2, cat2.L};   // d2.1 -> skip half of cat2
-  bout[7] = View{cat2.p, cat2.ctot, 0, cat2.L};    // mid2 -> first half of cat2
+  bout[3] = cat1.sub(d1);   // d1.1 -> skip half of cat1
+  bout[5] = cat2.sub(d2);   // d2.1 -> skip half of cat2
+  bout[7] = cat2.sub(0);    // mid2 -> first half of cat2
   bin[1] = bout[0];
   bin[2] = whole(u->b_ds[0], d0, H / 2);
   bin[3] = bout[2];
@@ -985,8 +1049,7 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in, const float*
   RUN(res_block(7));
   RUN(res_block(8));
   RUN(res_block(9));
-  RUN(run_conv(K_UP_F, H / 2,
-               conv_args(bout[9], u->up_f[0], u->up_bias[0], View{cat1.p, cat1.ctot, 0, cat1.L}, rows), st));
+  RUN(run_conv(K_UP_F, H / 2, conv_args(bout[9], u->up_f[0], u->up_bias[0], cat1.sub(0), rows), st));
   RUN(res_block(10));
   RUN(res_block(11));
   View up1 = whole(u->b_up1, d0, H);
@@ -1025,8 +1088,15 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
   const trace_unet_config& c = u->cfg;
   const int H = c.horizon;
   const int d0 = c.dims[0], d1 = c.dims[1], d2 = c.dims[2];
-  float *T1 = buf(u->b_T1), *T2 = buf(u->b_T2), *G0 = buf(u->b_G0), *G1 = buf(u->b_G1);
-  View dcat1{buf(u->b_dcat1), 2 * d1, 0, H / 2}, dcat2{buf(u->b_dcat2), 2 * d2, 0, H / 4};
+  t_zero_cell = u->zero_cell;
+  // views of the gradient scratch buffers with their plane twins; the same buffer is reused with different
+  // (channels, length) shapes, which is consistent as long as a tensor's producer and consumers agree
+  auto view = [&](int id, int C, int coff, int L) {
+    const int tw = u->buf_twin[id];
+    return View{buf(id), C, coff, L, tw >= 0 ? (void*)buf(tw) : nullptr};
+  };
+  const int iT1 = u->b_T1, iT2 = u->b_T2, iG0 = u->b_G0, iG1 = u->b_G1;
+  View dcat1 = view(u->b_dcat1, 2 * d1, 0, H / 2), dcat2 = view(u->b_dcat2, 2 * d2, 0, H / 4);
 
   // GroupNorm+Mish backward is fused into the epilogue of whichever dgrad conv PRODUCES the
   // gradient (set_gnb); only the very first one (after the head) runs as its own kernel.
@@ -1038,7 +1108,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
   //   dx = dgrad_c1(T2) [+ dgrad_res(dout) as extra K | + dout] [+ extra];  T1 = gnb(dx; y2_next)
   auto block_bwd = [&](int i, const View& dout, const View& dx, const View* extra, int next) -> int {
     const Block& b = u->blocks[i];
-    View t1{T1, b.cout, 0, b.L}, t2{T2, b.cout, 0, b.L};
+    View t1 = view(iT1, b.cout, 0, b.L), t2 = view(iT2, b.cout, 0, b.L);
     {
       ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
       set_gnb(a, buf(u->b_y1[i]), buf(u->b_s1[i]), b.g1, b.be1, b.cout, t2, nullptr);
@@ -1049,7 +1119,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
     if (extra) set_res2(a, *extra);
     if (next >= 0) {
       const Block& nb = u->blocks[next];
-      View nt1{T1, nb.cout, 0, nb.L};
+      View nt1 = view(iT1, nb.cout, 0, nb.L);
       set_gnb(a, buf(u->b_y2[next]), buf(u->b_s2[next]), nb.g2, nb.be2, nb.cout, nt1, &dx);
     }
     RUN(run_conv(K_CONV5, b.L, a, st));
@@ -1061,68 +1131,68 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
     ConvArgs a = conv_args(in, w, nullptr, dx, rows);
     if (res) set_res(a, *res);
     const Block& nb = u->blocks[next];
-    View nt1{T1, nb.cout, 0, nb.L};
+    View nt1 = view(iT1, nb.cout, 0, nb.L);
     set_gnb(a, buf(u->b_y2[next]), buf(u->b_s2[next]), nb.g2, nb.be2, nb.cout, nt1, &dx);
     return run_conv(kind, L_out, a, st);
   };
 
   // head + final block
   {
-    View g0{G0, d0, 0, H}, t1{T1, d0, 0, H}, g1{G1, d0, 0, H};
-    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, T1, d0, H, rows, st, grad_pred, u->head_w));
+    View g0 = view(iG0, d0, 0, H), g1 = view(iG1, d0, 0, H);
+    View t1 = view(iT1, d0, 0, H).no_planes();          // written by gn_mish_bwd_kernel: fp32 only
+    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, t1.p, d0, H, rows, st, grad_pred, u->head_w));
     RUN(run_conv(K_CONV5, H, conv_args(t1, u->final_b, nullptr, g1, rows), st));
   }
   // up1 (ConvT d0: L/2 -> L): its dgrad output is dout of block 11
-  RUN(resample_bwd(K_UP_B, H / 2, View{G1, d0, 0, H}, u->up_b[1], View{G0, d0, 0, H / 2}, nullptr, 11));
-  RUN(block_bwd(11, View{G0, d0, 0, H / 2}, View{G1, d0, 0, H / 2}, nullptr, 10));
-  RUN(block_bwd(10, View{G1, d0, 0, H / 2}, dcat1, nullptr, -1));
+  RUN(resample_bwd(K_UP_B, H / 2, view(iG1, d0, 0, H), u->up_b[1], view(iG0, d0, 0, H / 2), nullptr, 11));
+  RUN(block_bwd(11, view(iG0, d0, 0, H / 2), view(iG1, d0, 0, H / 2), nullptr, 10));
+  RUN(block_bwd(10, view(iG1, d0, 0, H / 2), dcat1, nullptr, -1));
   // up0 (ConvT d1: L/4 -> L/2) reads the first half of dcat1; output = dout of block 9
-  RUN(resample_bwd(K_UP_B, H / 4, View{dcat1.p, dcat1.ctot, 0, dcat1.L}, u->up_b[0],
-                   View{G0, d1, 0, H / 4}, nullptr, 9));
-  RUN(block_bwd(9, View{G0, d1, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr, 8));
+  RUN(resample_bwd(K_UP_B, H / 4, dcat1.sub(0), u->up_b[0], view(iG0, d1, 0, H / 4), nullptr, 9));
+  RUN(block_bwd(9, view(iG0, d1, 0, H / 4), view(iG1, d1, 0, H / 4), nullptr, 8));
   // block 8 writes dcat2 (2*d2 channels); only its first half is dout of mid2 (block 7)
   {
     const Block& b = u->blocks[8];
-    View t1{T1, b.cout, 0, b.L}, t2{T2, b.cout, 0, b.L};
+    View t1 = view(iT1, b.cout, 0, b.L), t2 = view(iT2, b.cout, 0, b.L);
     ConvArgs a2 = conv_args(t1, b.c2b, nullptr, t2, rows);
     set_gnb(a2, buf(u->b_y1[8]), buf(u->b_s1[8]), b.g1, b.be1, b.cout, t2, nullptr);
     RUN(run_conv(K_CONV5, b.L, a2, st));
     ConvArgs a = conv_args(t2, b.c1b, nullptr, dcat2, rows);
-    set_in2(a, View{G1, d1, 0, H / 4});
+    set_in2(a, view(iG1, d1, 0, H / 4));
     const Block& nb = u->blocks[7];
-    View nt1{T1, nb.cout, 0, nb.L};
+    View nt1 = view(iT1, nb.cout, 0, nb.L);
     set_gnb(a, buf(u->b_y2[7]), buf(u->b_s2[7]), nb.g2, nb.be2, nb.cout, nt1, &dcat2);
     RUN(run_conv(K_CONV5, b.L, a, st));
   }
   // mid2: dout = dcat2[0:d2]
-  RUN(block_bwd(7, View{dcat2.p, dcat2.ctot, 0, dcat2.L}, View{G0, d2, 0, H / 4}, nullptr, 6));
+  RUN(block_bwd(7, dcat2.sub(0), view(iG0, d2, 0, H / 4), nullptr, 6));
   // mid1: + skip gradient dcat2[d2:2*d2]
   {
-    View skip{dcat2.p, dcat2.ctot, d2, dcat2.L};
-    RUN(block_bwd(6, View{G0, d2, 0, H / 4}, View{G1, d2, 0, H / 4}, &skip, 5));
+    View skip = dcat2.sub(d2);
+    RUN(block_bwd(6, view(iG0, d2, 0, H / 4), view(iG1, d2, 0, H / 4), &skip, 5));
   }
-  RUN(block_bwd(5, View{G1, d2, 0, H / 4}, View{G0, d2, 0, H / 4}, nullptr, 4));
-  RUN(block_bwd(4, View{G0, d2, 0, H / 4}, View{G1, d1, 0, H / 4}, nullptr, -1));
+  RUN(block_bwd(5, view(iG1, d2, 0, H / 4), view(iG0, d2, 0, H / 4), nullptr, 4));
+  RUN(block_bwd(4, view(iG0, d2, 0, H / 4), view(iG1, d1, 0, H / 4), nullptr, -1));
   // down1 (Conv k3 s2 d1: L/2 -> L/4) + skip gradient dcat1[d1:2*d1]; output = dout of block 3
   {
-    View skip{dcat1.p, dcat1.ctot, d1, dcat1.L};
-    RUN(resample_bwd(K_DOWN_B, H / 2, View{G1, d1, 0, H / 4}, u->down_b[1], View{G0, d1, 0, H / 2}, &skip, 3));
+    View skip = dcat1.sub(d1);
+    RUN(resample_bwd(K_DOWN_B, H / 2, view(iG1, d1, 0, H / 4), u->down_b[1], view(iG0, d1, 0, H / 2), &skip, 3));
   }
-  RUN(block_bwd(3, View{G0, d1, 0, H / 2}, View{G1, d1, 0, H / 2}, nullptr, 2));
-  RUN(block_bwd(2, View{G1, d1, 0, H / 2}, View{G0, d0, 0, H / 2}, nullptr, -1));
+  RUN(block_bwd(3, view(iG0, d1, 0, H / 2), view(iG1, d1, 0, H / 2), nullptr, 2));
+  RUN(block_bwd(2, view(iG1, d1, 0, H / 2), view(iG0, d0, 0, H / 2), nullptr, -1));
   // down0 (Conv k3 s2 d0: L -> L/2); the level-0 skip is never consumed (temporal.py:129,134)
-  RUN(resample_bwd(K_DOWN_B, H, View{G0, d0, 0, H / 2}, u->down_b[0], View{G1, d0, 0, H}, nullptr, 1));
-  RUN(block_bwd(1, View{G1, d0, 0, H}, View{G0, d0, 0, H}, nullptr, 0));
+  RUN(resample_bwd(K_DOWN_B, H, view(iG0, d0, 0, H / 2), u->down_b[0], view(iG1, d0, 0, H), nullptr, 1));
+  RUN(block_bwd(1, view(iG1, d0, 0, H), view(iG0, d0, 0, H), nullptr, 0));
   // first block: only input channels [4,5] are needed (tbsim/models/trace.py:674-676)
   {
     const Block& b = u->blocks[0];
-    View t1{T1, d0, 0, H}, t2{T2, d0, 0, H};
+    View t1 = view(iT1, d0, 0, H), t2 = view(iT2, d0, 0, H).no_planes();      // t2 feeds first_dgrad_kernel (fp32)
     ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
     set_gnb(a, buf(u->b_y1[0]), buf(u->b_s1[0]), b.g1, b.be1, b.cout, t2, nullptr);
     RUN(run_conv(K_CONV5, b.L, a, st));
     TRACE_REQUIRE(H % 4 == 0, "first_dgrad: horizon %d not a multiple of 4", H);
     int n = rows * (H / 4);
-    hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, T2, G0,
+    hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t2.p, buf(iG0),
                        u->first_wsel, u->first_rsel, grad_x, d0, H, rows);
     RUN(launch_status("first_dgrad_kernel"));
   }
