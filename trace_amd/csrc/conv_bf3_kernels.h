@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
   const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wb) + ((size_t)(ct * 4 + cwave) * a.nsl) * 192 + lane;
 #ifndef TRACE_BF3_WPF
-#define TRACE_BF3_WPF 2           // weight slices in flight ahead of the one being multiplied
+#define TRACE_BF3_WPF 1           // weight slices in flight ahead of the one being multiplied
 #endif
 #ifndef TRACE_BF3_NST
 #define TRACE_BF3_NST 4           // A-fragment register stages (prefetch distance + 1)
@@ -321,6 +321,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
         }
       }
       if (n + DIST < NT) load_a(n + DIST, (n + DIST) % NST);
+#ifndef TRACE_BF3_PIN
+#define TRACE_BF3_PIN 1           // pin the LDS reads of tile n + DIST ahead of tile n's MFMAs (the scheduler sinks them otherwise)
+#endif
+      if constexpr (TRACE_BF3_PIN) __builtin_amdgcn_sched_barrier(0);
 #ifndef TRACE_BF3_LOAD_SPREAD
 #define TRACE_BF3_LOAD_SPREAD 0   // row tiles between the global loads of two staging units of the next chunk (0: all at once)
 #endif
@@ -353,6 +357,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[1], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[0], c, 0, 0, 0);
       acc[rt] = c;
+      if constexpr (TRACE_BF3_PIN) __builtin_amdgcn_sched_barrier(0);
     }
   };
 
