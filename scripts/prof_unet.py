@@ -16,9 +16,15 @@ table = torch.empty(rows // 20, s.cond_width, device="cuda:0")
 _cabi.check(L.trace_unet_cond_table(s._unet, cond.data_ptr(), rows // 20, table.data_ptr(), None))
 wsb = L.trace_unet_workspace_bytes(s._unet, rows, 1); ws = torch.empty(wsb, dtype=torch.uint8, device="cuda:0")
 pred = torch.empty(rows, 52, 2, device="cuda:0"); gp = torch.randn(rows, 52, 2, device="cuda:0", generator=g); gx = torch.empty(rows, 52, 2, device="cuda:0")
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 for i in range(iters):
+    if i == 1:
+        e0.record()          # the first pass warms up (kernel attributes, caches)
     _cabi.check(L.trace_unet_forward(s._unet, x_in.data_ptr(), table.data_ptr(), 20, 50, rows, pred.data_ptr(), ws.data_ptr(), wsb, 1, None))
     if bwd:
         _cabi.check(L.trace_unet_backward_input(s._unet, gp.data_ptr(), rows, gx.data_ptr(), ws.data_ptr(), wsb, None))
+e1.record()
 torch.cuda.synchronize()
+if iters > 1:
+    print("ms per pass (fwd%s): %.3f" % (" + input-VJP" if bwd else "", e0.elapsed_time(e1) / (iters - 1)))
 print("done", float(pred.abs().mean()), float(gx.abs().mean()) if bwd else 0)
