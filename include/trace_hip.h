@@ -290,6 +290,43 @@ int trace_env_rasterize(const float* pose, const int* scene_of_agent, const floa
                         const float* raster_from_agent_host, float* image, int channels,
                         uint8_t* drivable, int n_agents, int H, int W, void* stream);
 
+/* ---- map encoder: the layers of the reference's MapEncoder -- torchvision ResNet-18
+ * trunk behind RasterizedMapEncoder (tbsim/models/base_models.py:402-491) and MapGridDecoder
+ * (tbsim/models/trace_helpers.py:231-268; Up / DoubleConv / ConvBlock at base_models.py:169-260) -- as kernels.
+ * Activations are NHWC fp32 (B, H, W, ctot); a layer reads / writes the channel window [coff, coff + C) of its
+ * buffer, so the decoder's skip concatenations (base_models.py:224) are written in place.
+ *
+ * trace_conv2d: out = act(scale[co] * conv(in, w) + shift[co] (+ res)), cross-correlation as torch.nn.Conv2d.
+ *   evaluation-mode BatchNorm and the conv bias are folded into scale / shift by the caller (NULL = 1 / 0).
+ *   packed_w: the weight (cout, cin, kh, kw) split exactly into three bf16 planes and laid out in MFMA fragment
+ *   order [cout/16][cin/32][kh*kw][3 planes][64 lanes][8] (trace_amd/map_encoder.py pack_conv2d_weight);
+ *   fp32 products through 6 bf16 MFMA terms as in the denoiser.  cin % 32 == 0, cout % 16 == 0.
+ *   Built shapes: 3x3 s1 p1 at output widths 56/28/14/7, 3x3 s2 p1 and 1x1 s2 at 28/14/7, 1x1 s1 at 56 (a 224 x
+ *   224 raster); anything else returns TRACE_EINVAL. */
+int trace_conv2d(const float* in, int B, int H, int W, int in_ctot, int in_coff, int cin,
+                 const void* packed_w, int kh, int kw, int stride, int pad, float* out, int out_ctot,
+                 int out_coff, int cout, const float* scale, const float* shift, const float* res,
+                 int res_ctot, int res_coff, int relu, void* stream);
+
+/* ResNet stem: 7x7 stride-2 pad-3 conv of the NCHW raster (B, C <= 8, H, W) + BatchNorm + ReLU
+ * (torchvision resnet conv1/bn1/relu; C-channel stem at base_models.py:437-441) -> NHWC (B, H/2, W/2, 64).
+ *   w_tap_ci_co: the weight (64, C, 7, 7) permuted to (7, 7, C, 64), fp32. */
+int trace_map_stem(const float* image, const float* w_tap_ci_co, const float* scale, const float* shift,
+                   float* out, int B, int C, int H, int W, void* stream);
+
+/* MaxPool2d(3, stride 2, padding 1) of an NHWC tensor (torchvision resnet maxpool). C % 4 == 0. */
+int trace_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True) (base_models.py:211) of NHWC (B, H, W, C)
+ * into the channel window [out_coff, out_coff + C) of (B, 2H, 2W, out_ctot). */
+int trace_upsample2x(const float* in, float* out, int B, int H, int W, int C, int out_ctot, int out_coff,
+                     void* stream);
+
+/* nn.LayerNorm over ALL n elements of each image with an elementwise affine (trace_helpers.py:258,267);
+ * gamma / beta in the memory order of `in` (the caller permutes the (C, H, W) parameters to (H, W, C)). */
+int trace_layernorm_image(const float* in, const float* gamma, const float* beta, float* out, int B, int n,
+                          float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,7 @@ SOURCES = [
     ("unet.hip", ["-fno-slp-vectorize"]),
     ("steps.hip", ["-ffp-contract=off"]),
     ("guidance.hip", ["-ffp-contract=off"]),
+    ("conv2d.hip", ["-fno-slp-vectorize"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
           "-I", os.path.join(ROOT, "include"), "-I", CSRC]

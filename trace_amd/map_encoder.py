@@ -8,9 +8,13 @@ Structure restated from the reference
   * Up / DoubleConv / ConvBlock       /root/reference/tbsim/models/base_models.py:169-260
 and from torchvision's ResNet-18 (BasicBlock x [2,2,2,2]), whose layout the reference inherits.
 
-It runs ONCE per sampling call (amortised over the 100 diffusion steps), so it is plain PyTorch-ROCm
-ops on the device (MIOpen convolutions), evaluation-mode BatchNorm folded into scale/shift; it is
-not a kernel target of this build (SURVEY.md section 8 row A0, and (f)-2 for a later round).
+It runs ONCE per sampling call (amortised over the 100 diffusion steps).  On the GPU, for the
+224 x 224 rasters of every TRACE config, it runs on this library's own kernels (backend "hip",
+trace_amd/csrc/conv2d.hip: NHWC implicit-GEMM convolutions on the bf16 matrix pipe with fp32
+results, BatchNorm / bias / residual / ReLU fused, skip concatenations written in place; stem,
+max-pool, bilinear up-sampling and LayerNorm kernels) through the C ABI (include/trace_hip.h,
+SURVEY.md section 8(f)-2).  Backend "torch" is the same network as PyTorch-ROCm ops (MIOpen
+convolutions): the comparison path of the tests, and the path for other raster sizes and the CPU.
 
 PARITY UNPINNED: torchvision is absent from the build container, so the reference's encoder
 cannot be instantiated to emit golden vectors; the tests check this module
@@ -22,6 +26,8 @@ from collections import OrderedDict
 
 import torch
 import torch.nn.functional as F
+
+from . import _cabi
 
 PREFIX = "map_encoder."
 _TRUNK = "map_encoder.encoder_heads.map_model."
@@ -101,6 +107,22 @@ def random_map_encoder_state_dict(in_channels=2, grid_feature_dim=32, image_hw=(
     return sd
 
 
+def pack_conv2d_weight(w):
+    """Conv2d weight (cout, cin, kh, kw) fp32 -> the operand stream of trace_conv2d: every value split
+    exactly into three bf16 (w = h + m + l), laid out [cout/16][cin/32][kh*kw][plane][lane = 16 kq + col][8]
+    (MFMA B fragment of v_mfma_f32_16x16x32_bf16: lane holds input channels 8 kq .. 8 kq + 7 of output
+    channel col)."""
+    co, ci, kh, kw = w.shape
+    assert co % 16 == 0 and ci % 32 == 0, (co, ci)
+    x = w.detach().to(torch.float32).cpu().reshape(co // 16, 16, ci // 32, 4, 8, kh * kw)
+    x = x.permute(0, 2, 5, 3, 1, 4).contiguous()           # [col tile][chunk][tap][kq][col][j]
+    h = x.bfloat16()
+    r = x - h.float()
+    m = r.bfloat16()
+    l = (r - m.float()).bfloat16()
+    return torch.stack([h, m, l], dim=3).contiguous()
+
+
 def has_map_encoder(state_dict):
     return any(k.startswith(PREFIX) and k.endswith("map_model.conv1.weight") for k in state_dict)
 
@@ -115,9 +137,18 @@ class MapEncoder:
     # 489 ms, scripts/prof_map_encoder.py; max relative difference 3.9e-6) -- at the price of ~90 s of kernel compilation
     # the first time a process sees the shapes (MIOpen caches them on disk), which small calls do not repay.
     CHANNELS_LAST_FROM = 1024
+    # images per pass of the HIP backend: bounds the activation buffers (about 45 MB per image) and keeps a
+    # layer's producer -> consumer distance inside what L2 / MALL still hold
+    HIP_CHUNK = 256
 
-    def __init__(self, state_dict, device="cuda:0", channels_last_from=None):
+    def __init__(self, state_dict, device="cuda:0", channels_last_from=None, backend=None):
         self.device = torch.device(device)
+        self.backend = backend or ("hip" if self.device.type == "cuda" else "torch")
+        assert self.backend in ("hip", "torch")
+        if self.backend == "hip":
+            _cabi.lib()                    # fails loudly when the library is not built
+        self._hip = None
+        self._hip_bufs = {}
         self.channels_last_from = self.CHANNELS_LAST_FROM if channels_last_from is None else channels_last_from
         self._p_nhwc = None
         p = {}
@@ -176,6 +207,8 @@ class MapEncoder:
     @torch.no_grad()
     def __call__(self, image):
         x = image.to(device=self.device, dtype=torch.float32)
+        if self.backend == "hip" and tuple(x.shape[2:]) == (224, 224) and x.shape[1] <= 8:
+            return None, self._forward_hip(x.contiguous())
         nhwc = self.device.type == "cuda" and x.shape[0] >= self.channels_last_from
         if nhwc:
             if self._p_nhwc is None:
@@ -214,3 +247,137 @@ class MapEncoder:
         w, b = p[_DEC + "out_norm.weight"], p[_DEC + "out_norm.bias"]
         x = F.layer_norm(x.contiguous(), tuple(w.shape), w, b, _LN_EPS)
         return None, x
+
+    # ------------------------------------------------------------------ HIP backend
+    def _prepare_hip(self):
+        """Folds BatchNorm (+ conv bias) into per-channel scale / shift and packs the weights, once."""
+        p, dev = self._p_nchw, self.device
+
+        def fold(bn_prefix, bias=None):
+            scale = p[bn_prefix + ".weight"] / torch.sqrt(p[bn_prefix + ".running_var"] + _BN_EPS)
+            shift = p[bn_prefix + ".bias"] - p[bn_prefix + ".running_mean"] * scale
+            if bias is not None:
+                shift = shift + scale * bias
+            return scale.contiguous(), shift.contiguous()
+
+        def conv(wkey, bn_prefix=None, bias_key=None):
+            w = p[wkey]
+            bias = p[bias_key] if bias_key else None
+            if bn_prefix:
+                scale, shift = fold(bn_prefix, bias)
+            else:
+                scale, shift = None, (bias.contiguous() if bias is not None else None)
+            return {"w": pack_conv2d_weight(w).to(dev), "k": w.shape[2], "cin": w.shape[1], "cout": w.shape[0],
+                    "scale": scale, "shift": shift}
+
+        h = {"stem_w": p[_TRUNK + "conv1.weight"].permute(2, 3, 1, 0).contiguous()}
+        h["stem_scale"], h["stem_shift"] = fold(_TRUNK + "bn1")
+        for li in range(1, 5):
+            for bi in range(2):
+                q = "%slayer%d.%d." % (_TRUNK, li, bi)
+                h[q + "conv1"] = conv(q + "conv1.weight", q + "bn1")
+                h[q + "conv2"] = conv(q + "conv2.weight", q + "bn2")
+                if q + "downsample.0.weight" in p:
+                    h[q + "ds"] = conv(q + "downsample.0.weight", q + "downsample.1")
+        h["dec1"] = conv(_DEC + "conv1.0.weight")
+        for name in ("up1", "up2", "up3"):
+            q = "%s%s.conv.double_conv." % (_DEC, name)
+            h[name + "a"] = conv(q + "0.weight", q + "1", q + "0.bias")
+            h[name + "b"] = conv(q + "3.weight", q + "4", q + "3.bias")
+        q = _DEC + "conv2."
+        h["cb1"] = conv(q + "conv1.weight", q + "bn1")
+        h["cb2"] = conv(q + "conv2.weight", q + "bn2")
+        h["cb3"] = conv(q + "conv3.weight", q + "bn3")
+        h["cbs"] = conv(q + "shortcut.0.weight", q + "shortcut.1")
+        h["out"] = conv(_DEC + "conv3.weight", None, _DEC + "conv3.bias")
+        # LayerNorm parameters (C, H, W) -> the NHWC memory order of the activations
+        h["ln_w"] = p[_DEC + "out_norm.weight"].permute(1, 2, 0).contiguous()
+        h["ln_b"] = p[_DEC + "out_norm.bias"].permute(1, 2, 0).contiguous()
+        self._hip = h
+
+    def _buffers(self, n):
+        b = self._hip_bufs.get(n)
+        if b is None:
+            gd = self._p_nchw[_DEC + "conv3.weight"].shape[0]
+
+            def e(hw, c):
+                return torch.empty(n, hw, hw, c, device=self.device, dtype=torch.float32)
+
+            b = {"s0": e(112, 64), "cat3": e(56, 192), "a56": e(56, 64), "b56": e(56, 64), "c56": e(56, 64),
+                 "cat2": e(28, 384), "a28": e(28, 128), "b28": e(28, 128), "c28": e(28, 128),
+                 "cat1": e(14, 768), "a14": e(14, 256), "b14": e(14, 256), "c14": e(14, 256),
+                 "a7": e(7, 512), "b7": e(7, 512), "c7": e(7, 512), "d7": e(7, 512),
+                 "m14": e(14, 384), "u1": e(14, 256), "m28": e(28, 192), "u2": e(28, 128),
+                 "m56": e(56, 96), "u3": e(56, 64), "o32": e(56, gd)}
+            self._hip_bufs = {n: b}          # one chunk size resident at a time
+        return b
+
+    def _conv(self, n, L, src, dst, stride=1, relu=True, res=None):
+        """src / dst / res: (tensor, first channel).  One trace_conv2d launch."""
+        (x, xoff), (y, yoff) = src, dst
+        k = L["k"]
+        r, roff = res if res is not None else (None, 0)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _cabi.check(_cabi.lib().trace_conv2d(
+            x.data_ptr(), n, x.shape[1], x.shape[2], x.shape[3], xoff, L["cin"], L["w"].data_ptr(), k, k, stride,
+            k // 2, y.data_ptr(), y.shape[3], yoff, L["cout"], _cabi.ptr(L["scale"]), _cabi.ptr(L["shift"]),
+            _cabi.ptr(r), r.shape[3] if r is not None else 0, roff, 1 if relu else 0, st), "trace_conv2d")
+
+    def _forward_hip(self, image):
+        if self._hip is None:
+            self._prepare_hip()
+        h, lib = self._hip, _cabi.lib()
+        B, C = image.shape[:2]
+        gd = self._p_nchw[_DEC + "conv3.weight"].shape[0]
+        out = torch.empty(B, 56, 56, gd, device=self.device, dtype=torch.float32)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            for i0 in range(0, B, self.HIP_CHUNK):
+                n = min(self.HIP_CHUNK, B - i0)
+                b = self._buffers(min(self.HIP_CHUNK, B))
+                cv = lambda *a, **k: self._conv(n, *a, **k)
+                _cabi.check(lib.trace_map_stem(image[i0:].data_ptr(), h["stem_w"].data_ptr(),
+                                               h["stem_scale"].data_ptr(), h["stem_shift"].data_ptr(),
+                                               b["s0"].data_ptr(), n, C, 224, 224, st), "trace_map_stem")
+                _cabi.check(lib.trace_maxpool3x3s2(b["s0"].data_ptr(), b["a56"].data_ptr(), n, 112, 112, 64, st),
+                            "trace_maxpool3x3s2")
+                # trunk: torchvision BasicBlock = relu(bn2(conv2(relu(bn1(conv1(x))))) + identity); the last block
+                # of a layer writes its output into the skip window of the decoder's concatenation buffer
+                x = (b["a56"], 0)
+                for li, (ta, tb, tc, dst) in enumerate((("a56", "b56", "c56", ("cat3", 0)),
+                                                        ("a28", "b28", "c28", ("cat2", 0)),
+                                                        ("a14", "b14", "c14", ("cat1", 0)),
+                                                        ("a7", "b7", "c7", ("d7", 0))), start=1):
+                    q0, q1 = "%slayer%d.0." % (_TRUNK, li), "%slayer%d.1." % (_TRUNK, li)
+                    if li == 1:
+                        cv(h[q0 + "conv1"], x, (b[tb], 0))
+                        cv(h[q0 + "conv2"], (b[tb], 0), (b[tc], 0), res=x)
+                    else:
+                        cv(h[q0 + "conv1"], x, (b[ta], 0), stride=2)
+                        cv(h[q0 + "ds"], x, (b[tb], 0), stride=2, relu=False)
+                        cv(h[q0 + "conv2"], (b[ta], 0), (b[tc], 0), res=(b[tb], 0))
+                    t = tb if li == 1 else ta
+                    cv(h[q1 + "conv1"], (b[tc], 0), (b[t], 0))
+                    cv(h[q1 + "conv2"], (b[t], 0), (b[dst[0]], dst[1]), res=(b[tc], 0))
+                    x = (b[dst[0]], dst[1])
+                # MapGridDecoder.forward, trace_helpers.py:259-268
+                cv(h["dec1"], (b["d7"], 0), (b["a7"], 0))
+                src = b["a7"]
+                for name, cat, skip_c, mid, o in (("up1", "cat1", 256, "m14", "u1"), ("up2", "cat2", 128, "m28", "u2"),
+                                                  ("up3", "cat3", 64, "m56", "u3")):
+                    _cabi.check(lib.trace_upsample2x(src.data_ptr(), b[cat].data_ptr(), n, src.shape[1], src.shape[2],
+                                                     src.shape[3], b[cat].shape[3], skip_c, st), "trace_upsample2x")
+                    cv(h[name + "a"], (b[cat], 0), (b[mid], 0))
+                    cv(h[name + "b"], (b[mid], 0), (b[o], 0))
+                    src = b[o]
+                # ConvBlock, base_models.py:229-260
+                cv(h["cb1"], (b["u3"], 0), (b["a56"], 0))
+                cv(h["cb2"], (b["a56"], 0), (b["b56"], 0))
+                cv(h["cbs"], (b["u3"], 0), (b["c56"], 0), relu=False)
+                cv(h["cb3"], (b["b56"], 0), (b["a56"], 0), res=(b["c56"], 0))
+                cv(h["out"], (b["a56"], 0), (b["o32"], 0), relu=False)
+                _cabi.check(lib.trace_layernorm_image(b["o32"].data_ptr(), h["ln_w"].data_ptr(), h["ln_b"].data_ptr(),
+                                                      out[i0:].data_ptr(), n, 56 * 56 * gd, _LN_EPS, st),
+                            "trace_layernorm_image")
+        # (B, C, H, W) logical shape of the reference on channels-last memory: the sampler's grid layout
+        return out.permute(0, 3, 1, 2)
