@@ -104,6 +104,12 @@ int trace_unet_backward_input(trace_unet* u, const float* grad_pred, int rows, f
 int trace_profile_begin(int max_launches);
 int trace_profile_end(double* total_ms, int64_t* launches, double* total_flops);
 
+/* Kernel choice for the full-chip multi-tap convolutions of the denoiser: 0 = conv_bf3_kernel (two workgroups
+ * per CU, the default), 1 = conv_ws_kernel (persistent, wave-specialised: csrc/conv_ws_kernels.h), -1 = leave
+ * as is.  Both give the same bits; the switch exists for A/B measurements and tests.  Initial value: environment
+ * variable TRACE_CONV_WS (default 0).  Returns the previous value.  No counterpart in the reference. */
+int trace_conv_ws_mode(int mode);
+
 #ifdef TRACE_CONV_STAMPS
 /* Diagnostic builds only (scripts/stamps.py builds a second library with -DTRACE_CONV_STAMPS): conv launch
  * number `launch_index` after this call writes 16 s_memtime stamps per workgroup into `buf` (device). */

@@ -355,3 +355,46 @@ def test_every_denoiser_buffer_is_bit_reproducible(full):
         assert n == 0, "%s: %d differing words of %d" % (name, n, a.numel())
     assert bool(torch.isfinite(runs[0][2].view(torch.float32)).all())
     assert float(runs[0][3].view(torch.float32).abs().max()) > 0
+
+
+def test_wave_specialised_conv_kernel_gives_the_same_bits(full):
+    """conv_ws_kernel (persistent, wave-specialised; csrc/conv_ws_kernels.h, opt-in through trace_conv_ws_mode) against
+    the default conv_bf3_kernel: every buffer of the denoiser workspace after the forward and after the input-VJP,
+    the prediction and the input gradient, bit for bit at 10240 rows, plus a ragged row count (tail tiles)."""
+    from trace_amd import _cabi
+    f = full
+    s, cfg, N = f["s"], f["cfg"], f["N"]
+    L = _cabi.lib()
+    x = f["x0"].to(DEV)
+    M = x.shape[0]
+    aux = s.get_aux_info({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in f["batch"].items()}, True)
+    _, _, x_in, _ = s.denoise(x, 60, aux, N, w=0.5, save=False)
+    cond_rows = torch.cat([aux["cond_feat"], aux["non_cond_feat"]], 0).contiguous()
+    table = torch.empty(cond_rows.shape[0], s.cond_width, device=DEV)
+    _cabi.check(L.trace_unet_cond_table(s._unet, cond_rows.data_ptr(), cond_rows.shape[0], table.data_ptr(), None))
+    prev = L.trace_conv_ws_mode(-1)
+    try:
+        for R in (2 * M, 2 * M - 20 * 7):          # full, and a row count that leaves ragged tiles at every level
+            ws_bytes = L.trace_unet_workspace_bytes(s._unet, R, 1)
+            gpred = torch.randn(R, cfg.horizon, 2, generator=torch.Generator().manual_seed(31)).to(DEV)
+            runs = []
+            for mode in (0, 1):
+                L.trace_conv_ws_mode(mode)
+                ws = torch.zeros(ws_bytes // 4, dtype=torch.int32, device=DEV)
+                pred = torch.zeros(R, cfg.horizon, 2, device=DEV)
+                gx = torch.zeros(R, cfg.horizon, 2, device=DEV)
+                _cabi.check(L.trace_unet_forward(s._unet, x_in.data_ptr(), table.data_ptr(), N, 60, R, pred.data_ptr(),
+                                                 ws.data_ptr(), ws_bytes, 1, None), "trace_unet_forward")
+                torch.cuda.synchronize()
+                fwd = ws.clone()
+                _cabi.check(L.trace_unet_backward_input(s._unet, gpred.data_ptr(), R, gx.data_ptr(), ws.data_ptr(),
+                                                        ws_bytes, None), "trace_unet_backward_input")
+                torch.cuda.synchronize()
+                runs.append((fwd, ws, pred.view(torch.int32), gx.view(torch.int32)))
+            for name, a, b in zip(("workspace after the forward", "workspace after the input-VJP", "pred", "grad_x"),
+                                  runs[0], runs[1]):
+                n = int((a != b).sum())
+                assert n == 0, "R = %d, %s: %d differing words of %d" % (R, name, n, a.numel())
+            assert float(runs[1][3].view(torch.float32).abs().max()) > 0
+    finally:
+        L.trace_conv_ws_mode(prev)

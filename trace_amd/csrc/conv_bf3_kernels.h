@@ -314,10 +314,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
           for (int p = 0; p < 3; ++p) b[p] = bn1[p];
           ++sdone;
           wp += 192;
+#ifndef TRACE_EXP_NOWLOAD
           if (sdone < a.nsl) {
 #pragma unroll
             for (int p = 0; p < 3; ++p) bn1[p] = wp[64 * p];
           }
+#endif
         }
       }
       if (n + DIST < NT) load_a(n + DIST, (n + DIST) % NST);
@@ -377,17 +379,26 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     if constexpr (PLN) {
       stage_dma(ch);            // the barrier below waits for it (vmcnt(0) ahead of the s_barrier)
     } else {
+#ifdef TRACE_EXP_NOSTAGE
+      if (ch == 0)
+#endif
+      {
       if (!SPLITK || ch == 0) {
 #pragma unroll
         for (int j = 0; j < NUT; ++j) split_unit(j);
       }
       stage_write();
+      }
     }
     if (ch == 0) TRACE_STAMP(15);
     __syncthreads();
     if (ch == 0) TRACE_STAMP(1);
     // with the in-K split the body is branch-free: the last chunk re-stages itself (never written)
+#ifdef TRACE_EXP_NOSTAGE
+    const int next = -1;
+#else
     const int next = PLN ? -1 : (ch + 1 < nch ? ch + 1 : (SPLITK ? ch : -1));
+#endif
     using IC0 = std::integral_constant<int, 0>;
     using ICT = std::integral_constant<int, TAPS>;
     using ICP = std::integral_constant<int, PADL>;
@@ -416,6 +427,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   if constexpr (TRACE_BF3_EPI_REGS && NW == 4) {
     if (!a.gnb) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0); return; }
   }
+#ifdef TRACE_EXP_NOEPI
+  if (a.rows >= 0) {        // timing-only build: the accumulators stay live, the epilogue never runs
+    if (a.rows == 123456789) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) t += (acc[i][0] + acc[i][1]) + (acc[i][2] + acc[i][3]);
+      a.out[tid] = t;
+    }
+    return;
+  }
+#endif
   conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw);
 }
 
@@ -460,13 +482,15 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
                 "conv(bf16x3): output / residual tensors must be 16-byte aligned per trajectory tile and "
                 "below 4 GiB (%d rows)", a.rows);
   TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
-  constexpr size_t lds_bytes = G::LDS_BYTES;
-  static_assert(lds_bytes <= 80 * 1024, "conv(bf16x3): LDS per workgroup too large for two per CU");
+  static_assert(G::LDS_BYTES <= 80 * 1024, "conv(bf16x3): LDS per workgroup too large for two per CU");
+  // TRACE_EXP_ONE_WG=1 (experiment): pad the LDS request so that only ONE workgroup fits a CU
+  static const bool one_wg = getenv("TRACE_EXP_ONE_WG") && atoi(getenv("TRACE_EXP_ONE_WG")) != 0;
+  const size_t lds_bytes = one_wg ? (size_t)100 * 1024 : G::LDS_BYTES;
   static unsigned long long attr_done = 0;      // one bit per device
   if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, NW, MINW>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   }
   const int nrb = (a.rows + TB - 1) / TB;
   dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 64));
@@ -487,11 +511,23 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
 #ifndef TRACE_BF3_SMALL_NW
 #define TRACE_BF3_SMALL_NW 16
 #endif
+#ifndef TRACE_CONV_WS_DEFAULT
+#define TRACE_CONV_WS_DEFAULT 0
+#endif
+template <int L_OUT, int UP, int TAPS, int PADL, int TB>
+int launch_conv_ws(const ConvArgs& a_in, hipStream_t st);      // conv_ws_kernels.h
+int conv_ws_mode(int mode);                                    // unet.hip (trace_conv_ws_mode)
+
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
   if (a.inp && (a.cin2 == 0 || a.in2p)) return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, true>(a, st);
   const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
   static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
+  // full-chip launches of the multi-tap convs: the persistent wave-specialised kernel (conv_ws_kernels.h)
+  if constexpr (TAPS > 1) {
+    if (conv_ws_mode(-1) && wgs > small_max && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp)
+      return launch_conv_ws<L_OUT, UP, TAPS, PADL, TB>(a, st);
+  }
   if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max)
     return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
   return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false>(a, st);

@@ -7,8 +7,33 @@
 #include <vector>
 
 #include "conv_bf3_kernels.h"
+#include "conv_ws_kernels.h"
 
 namespace trace {
+
+int conv_ws_mode(int mode) {
+  static int cur = -1;
+  int prev = __atomic_load_n(&cur, __ATOMIC_ACQUIRE);
+  if (prev < 0) {
+    const char* e = getenv("TRACE_CONV_WS");
+    prev = e ? (atoi(e) != 0) : TRACE_CONV_WS_DEFAULT;
+    __atomic_store_n(&cur, prev, __ATOMIC_RELEASE);
+  }
+  if (mode >= 0) __atomic_store_n(&cur, mode != 0, __ATOMIC_RELEASE);
+  return prev;
+}
+
+int conv_ws_num_cus() {
+  static int cus[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+  int n = __atomic_load_n(&cus[dev], __ATOMIC_ACQUIRE);
+  if (n == 0) {
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    __atomic_store_n(&cus[dev], n, __ATOMIC_RELEASE);
+  }
+  return n;
+}
 
 static thread_local char g_err[512] = "";
 void set_error(const char* fmt, ...) {
@@ -1200,6 +1225,8 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
 }
 
 // ---- profiling entry points ---------------------------------------------------------------
+extern "C" int trace_conv_ws_mode(int mode) { return trace::conv_ws_mode(mode); }
+
 extern "C" int trace_profile_begin(int max_launches) {
   TRACE_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), "trace_profile_begin: bad size");
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
