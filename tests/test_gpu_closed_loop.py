@@ -186,3 +186,46 @@ def test_env_rasterize_kernel_vs_pixel_loop_and_torch():
     ms = e0.elapsed_time(e1) / 5
     gb = p.shape[0] * H * W * (4 * C + 1) / 1e9
     print("env_rasterize: %.3f ms for %d agents, %.0f GB/s written" % (ms, p.shape[0], gb / (ms * 1e-3)))
+
+
+def test_nuscenes_shaped_replan_with_seven_channel_raster():
+    """The nuScenes-shaped variant of the closed loop (configs/eval/nusc/target_pos.json:175-188 of the reference: a
+    7-layer semantic raster): the environment rasterises 7 channels, the checkpoint carries a 7-channel stem, and one
+    guided replanning call goes image -> HIP map encoder -> sampler.  Checked against the same call with the map
+    encoder on PyTorch-ROCm ops (the encoder's own checker, tests/test_gpu_map_encoder.py) and for determinism."""
+    import dataclasses
+    from trace_amd import synthetic as syn
+    from trace_amd.config import ModelConfig
+    from trace_amd.map_encoder import MapEncoder, random_map_encoder_state_dict
+    from trace_amd.policy import DiffuserTrafficModel, PolicyWrapper
+    from trace_amd.scene_edit import compute_heuristic_guidance
+    from trace_amd.sim_env import SceneBatchEnv
+    from trace_amd.weights import random_state_dict
+
+    cfg = dataclasses.replace(ModelConfig(), image_shape=(7, 224, 224))
+    dev = torch.device("cuda:0")
+    sd = dict(random_state_dict(cfg, 0))
+    sd.update(random_map_encoder_state_dict(7, cfg.map_grid_feature_dim, (224, 224), seed=3))
+    env = SceneBatchEnv(cfg, [6, 5], device=dev, seed=5, num_simulation_steps=40, area=14.0)
+    env.reset(scene_indices=[0, 1])
+    B = env.current_num_agents
+    heur = [{"name": "agent_collision", "weight": 1000.0, "params": {"num_disks": 1, "buffer_dist": 0.2}},
+            {"name": "target_pos", "weight": 30000.0, "params": {"target_time": 40}}]
+    guidance = compute_heuristic_guidance(heur, env, [0, 1], None)
+    env.reset(scene_indices=[0, 1])
+    obs = dict(env.get_observation()["agents"])
+    assert obs["image"].shape == (B, 7, 224, 224)
+    N, n_steps = 4, 10
+    init, steps = syn.make_noise(cfg, B, N, seed=9)
+    outs = []
+    for backend in ("hip", "hip", "torch"):
+        model = DiffuserTrafficModel(cfg, sd, dev, map_encoder=MapEncoder(sd, dev, backend=backend))
+        assert model.sampler.map_encoder.backend == backend
+        model.set_guidance(guidance, obs)
+        out = model.sampler(obs, num_samp=N, class_free_guide_w=0.5, guide_clean=True, noise_init=init,
+                            noise_steps=steps, n_steps=n_steps)
+        outs.append(out["pred_traj_scaled"].cpu())
+    assert bool(torch.isfinite(outs[0]).all())
+    assert torch.equal(outs[0], outs[1])                                 # same bits from two fresh models
+    err = float(((outs[0] - outs[2]).abs() / (1 + outs[2].abs())).max())
+    assert err < 2e-4, err                                              # encoder round-off (5e-6) through 10 guided steps

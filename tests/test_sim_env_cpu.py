@@ -156,9 +156,16 @@ def test_guided_rollout_closed_loop():
     assert model.calls == [0, 5, 10, 15]
     assert model.guidance is None                      # cleared at the end
     assert info["scene_index"] == ["scene_000000", "scene_000002"]
-    assert set(stats) == {"ade", "fde", "coll", "offroad"}
-    for v in stats.values():
+    # the per-guidance success metrics ride along under the reference's key names (guidance_metrics.py:496-510)
+    guide = {"guide_%s_s%dg0" % (m, s) for m in ("agent_collision", "agent_collision_disk", "social_dist")
+             for s in (0, 1)}
+    assert set(stats) == {"ade", "fde", "coll", "offroad"} | guide
+    for k, v in stats.items():
         assert v.shape == (2,)
+        if k in guide:                                                 # NaN but for the metric's own scene
+            own = int(k.split("_s")[-1][0])
+            assert np.isnan(v[1 - own]) and 0.0 <= v[own] <= 1.0
+    assert set(env._metrics) == {"coll", "offroad"}                    # removed again after the rollout
     # the constant-velocity plan reproduces the recorded future
     assert float(stats["ade"].max()) < 1e-3 and float(stats["fde"].max()) < 1e-3
     assert env.is_done()

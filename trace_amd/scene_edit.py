@@ -48,7 +48,9 @@ def guided_rollout(env, policy, policy_model, n_step_action=1, guidance_config=N
             ex_obs = _to_torch(ex_obs, device)
         if not use_gt:
             policy_model.set_guidance(guidance_config, ex_obs["agents"])
-        if guidance_metrics_fn is not None:
+        if guidance_metrics_fn is None:
+            from .guidance_metrics import guidance_metrics_from_config as guidance_metrics_fn
+        if guidance_metrics_fn:
             gm = guidance_metrics_fn(guidance_config)
             env._metrics.update(gm)
             added_metrics += list(gm.keys())

@@ -380,11 +380,26 @@ class SceneBatchEnv:
         new = torch.stack([wx, wy, wyaw], -1)                          # (B, n, 3)
         prev = torch.cat([self._hist[:, -1:, :2], new[:, :-1, :2]], 1)
         spd = torch.linalg.norm(new[..., :2] - prev, dim=-1) / self.cfg.step_time
-        for k in range(n):
-            step_obs = {"centroid": new[:, k, :2], "yaw": new[:, k, 2], "extent": self._extent_t,
-                        "scene_index": obs["scene_index"], "boxes": self._boxes[self._scene_index]}
-            for m in self._metrics.values():
-                m.add_step(step_obs, self.current_scene_index)
+        # Metrics see the state BEFORE each action is applied, with the map of the observation the plan was made
+        # from (env_trajdata.py:345-358): frame 0 is the current state, frame k the state after k actions.
+        if self._metrics:
+            pre = torch.cat([cur[:, None, :], new[:, :n - 1]], 1)          # (B, n, 3)
+            pre_spd = torch.cat([self._hist_speed[:, -1:], spd[:, :n - 1]], 1)
+            for k in range(n):
+                pk = pre[:, k]
+                ck, sk = torch.cos(pk[:, 2]), torch.sin(pk[:, 2])
+                afw = torch.zeros(pk.shape[0], 3, 3, device=self.device)
+                afw[:, 0, 0], afw[:, 0, 1], afw[:, 1, 0], afw[:, 1, 1], afw[:, 2, 2] = ck, sk, -sk, ck, 1.0
+                afw[:, 0, 2] = -(ck * pk[:, 0] + sk * pk[:, 1])
+                afw[:, 1, 2] = -(-sk * pk[:, 0] + ck * pk[:, 1])
+                step_obs = {"centroid": pk[:, :2], "yaw": pk[:, 2], "extent": self._extent_t,
+                            "curr_speed": pre_spd[:, k], "agent_from_world": afw,
+                            "scene_index": obs["scene_index"], "boxes": self._boxes[self._scene_index],
+                            "raster_from_world": obs["raster_from_world"]}
+                if "drivable_map" in obs:
+                    step_obs["drivable_map"], step_obs["image"] = obs["drivable_map"], obs["image"]
+                for m in self._metrics.values():
+                    m.add_step(step_obs, self.current_scene_index)
         # ADE / FDE against the recorded future
         dt = self.cfg.step_time
         kk = (self._frame_index + 1 + torch.arange(n, device=self.device, dtype=torch.float32)) * dt
