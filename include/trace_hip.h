@@ -110,6 +110,16 @@ int trace_profile_end(double* total_ms, int64_t* launches, double* total_flops);
  * variable TRACE_CONV_WS (default 0).  Returns the previous value.  No counterpart in the reference. */
 int trace_conv_ws_mode(int mode);
 
+/* Operand scheme of the denoiser's implicit-GEMM convolutions (fp32 results either way): 1 (default) = every fp32
+ * operand as TWO fp16 terms, three v_mfma_f32_16x16x32_f16 per product, the operands brought into fp16's exponent
+ * range by exact powers of two (weights: per layer on the host; activations: per 16 trajectories from the largest
+ * |value| the producing kernel recorded) -- used by every launch whose inputs all carry such a scale, the others
+ * stay on 0; 0 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per product everywhere; -1 = leave as is.  The
+ * wave-specialised kernel (trace_conv_ws_mode) only runs under scheme 0.  Initial value: environment variable
+ * TRACE_CONV_SCHEME ("bf16x3" / "fp16x2", default fp16x2).  Returns the previous value.  No counterpart in the
+ * reference (tbsim/models/temporal.py runs torch fp32 convolutions). */
+int trace_conv_scheme(int mode);
+
 #ifdef TRACE_CONV_STAMPS
 /* Diagnostic builds only (scripts/stamps.py builds a second library with -DTRACE_CONV_STAMPS): conv launch
  * number `launch_index` after this call writes 16 s_memtime stamps per workgroup into `buf` (device). */

@@ -87,6 +87,7 @@ PROTOTYPES = {
     "trace_guide_social_group": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _P, _P, _P, _P]),
     "trace_conv2d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),
     "trace_conv_ws_mode": (_I, [_I]),
+    "trace_conv_scheme": (_I, [_I]),
     "trace_map_stem": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "trace_maxpool3x3s2": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "trace_upsample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

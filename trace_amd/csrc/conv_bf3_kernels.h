@@ -82,10 +82,19 @@ struct Bf3Geom {
 // PLN: the input is staged from pre-split bf16 plane tensors (ConvArgs::inp / in2p) by LDS-DMA loads; otherwise
 // from the fp32 tensor through registers with the split in the kernel.
 // MINW = waves per SIMD the register budget is sized for (2: up to 256 VGPRs)
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int NW = TRACE_BF3_NW,
+// SCH = 0: three bf16 planes, six MFMAs per product (header of this file).
+// SCH = 1: TWO fp16 planes, a s = h + l with s a power of two that brings the operand into fp16's range (the
+//          weights' on the host, the activations' from the amax their producer recorded per 16 trajectories), and
+//          the three terms  l*h' + h*l' + h*h'  on v_mfma_f32_16x16x32_f16 (the dropped l*l' is below 2^-22 of the
+//          product; MFMA honours fp16 subnormal inputs, so small low terms degrade gracefully).  Measured against
+//          an fp64 sum at K = 1280 (scripts/probe/f16x2.hip): rms relative error 3.6e-7 (bf16 x 3: 5.3e-7, the fp32
+//          MFMA 5.8e-7 -- half the fp32 accumulations), at twice the rate.  Same LDS image, tile and epilogue.
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
           int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4>
 __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW>;
+  static_assert(SCH == 0 || (SCH == 1 && !PLN), "two schemes; the plane tensors are bf16 x 3 only");
+  constexpr int NPL = SCH == 1 ? 2 : 3;
   constexpr int LP = G::LP, L_IN = G::L_IN, SUB = G::SUB, PLANE = G::PLANE;
   constexpr int NUT = G::NUT, NU = G::NU, NPOS = G::NPOS, CH = G::CH, NTH = G::NTH, NACC = G::NACC;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -116,6 +125,22 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     a.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
   }
 #endif
+  // fp16 scheme: the activations of this workgroup's trajectories are multiplied by 2^(14 - E), E = exponent of
+  // the largest |value| of their group of 16 (both K sources share the accumulators, hence one scale), so the
+  // scaled maximum lies in [2^14, 2^15); the accumulators are scaled back by 2^-(14 - E) 2^-wexp
+  float ascale = 1.f, oscale = 1.f;
+  if constexpr (SCH == 1) {
+    unsigned am = __hip_atomic_load(a.in_amax + (traj0 >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.cin2) {
+      const unsigned am2 = __hip_atomic_load(a.in2_amax + (traj0 >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      am = am > am2 ? am : am2;
+    }
+    int ef = (int)(__builtin_amdgcn_readfirstlane(am) >> 23);
+    ef = ef < 87 ? 87 : (ef > 167 ? 167 : ef);            // |max| clamped to [2^-40, 2^40]
+    const int sf = 268 - ef;                               // exponent field of 2^(14 - E)
+    ascale = __builtin_bit_cast(float, (unsigned)sf << 23);
+    oscale = __builtin_bit_cast(float, (unsigned)(254 - sf - a.wexp) << 23);
+  }
 
   // ---- staging ------------------------------------------------------------------------------
   const int nch1 = a.cin / CH;
@@ -207,8 +232,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 #define TRACE_BF3_SPLIT_IN_K 0    // split the next chunk into bf16 planes between the MFMAs of the current one
 #endif
   constexpr bool SPLITK = TRACE_BF3_SPLIT_IN_K && TAPS > 1 && !PLN;     // the 1x1 kernels have no MFMA shadow to hide it in
-  u32x4v sph[NUTR], spm[NUTR], spl[NUTR];
-  auto split_unit = [&](int j) { if constexpr (!PLN) split8_bf16(stg[j], sph[j], spm[j], spl[j]); };
+  u32x4v sph[NUTR], spm[SCH == 1 ? 1 : NUTR], spl[NUTR];
+  auto split_unit = [&](int j) {
+    if constexpr (SCH == 1) split8_f16(stg[j], ascale, sph[j], spl[j]);
+    else if constexpr (!PLN) split8_bf16(stg[j], sph[j], spm[j], spl[j]);
+  };
   // the bf16 planes of the staged chunk go to LDS from sph / spm / spl
   auto stage_write = [&]() {
     if constexpr (!PLN) {
@@ -217,8 +245,12 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
         if ((NU % NTH == 0) || (tid + NTH * j < NU)) {
           char* p = ldsb + wofs[j];
           *reinterpret_cast<u32x4v*>(p) = sph[j];
-          *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
-          *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = spl[j];
+          if constexpr (SCH == 1) {
+            *reinterpret_cast<u32x4v*>(p + PLANE) = spl[j];
+          } else {
+            *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
+            *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = spl[j];
+          }
         }
       }
     }
@@ -231,7 +263,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     if constexpr (UP == 1 && TAPS == 1) {
     } else if constexpr (UP == 1) {
       constexpr int HALO = LP - L_IN;                      // PADL cells in front of the data, the rest behind
-      for (int i = tid; i < 12 * TB * HALO; i += NTH) {    // (plane, octet) arrays x trajectories x halo cells
+      for (int i = tid; i < 4 * NPL * TB * HALO; i += NTH) {    // (plane, octet) arrays x trajectories x halo cells
         const int arr = i / (TB * HALO);
         const int r0 = i - arr * (TB * HALO);
         const int tr = r0 / HALO;
@@ -241,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
       }
     } else {
 #pragma unroll 2
-      for (int i = tid; i < 3 * PLANE / 16; i += NTH)
+      for (int i = tid; i < NPL * PLANE / 16; i += NTH)
         reinterpret_cast<u32x4v*>(ldsb)[i] = u32x4v{0u, 0u, 0u, 0u};
     }
   }
@@ -264,19 +296,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   for (int rt = 0; rt < NACC; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wb) + ((size_t)(ct * 4 + cwave) * a.nsl) * 192 + lane;
+  constexpr int WSL = 64 * NPL;                  // fragments per slice
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(SCH == 1 ? a.wh : a.wb) + ((size_t)(ct * 4 + cwave) * a.nsl) * WSL + lane;
 #ifndef TRACE_BF3_WPF
 #define TRACE_BF3_WPF 1           // weight slices in flight ahead of the one being multiplied
 #endif
 #ifndef TRACE_BF3_NST
 #define TRACE_BF3_NST 4           // A-fragment register stages (prefetch distance + 1)
 #endif
-  bf16x8 bn1[3], bn2[3];
+  bf16x8 bn1[NPL], bn2[NPL];
 #pragma unroll
-  for (int p = 0; p < 3; ++p) bn1[p] = wp[64 * p];
+  for (int p = 0; p < NPL; ++p) bn1[p] = wp[64 * p];
   if constexpr (TRACE_BF3_WPF >= 2) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) bn2[p] = a.nsl > 1 ? wp[192 + 64 * p] : bn1[p];
+    for (int p = 0; p < NPL; ++p) bn2[p] = a.nsl > 1 ? wp[WSL + 64 * p] : bn1[p];
   }
   int sdone = 0;
 
@@ -287,37 +320,37 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NR = decltype(nrc)::value;
     constexpr int NT = (T1 - T0) * NR;
     constexpr int NST = TAPS == 1 ? (TRACE_BF3_NST < 3 ? TRACE_BF3_NST : 3) : TRACE_BF3_NST, DIST = NST - 1;   // A register stages / prefetch distance in tiles
-    bf16x8 av[NST][3];
+    bf16x8 av[NST][NPL];
     auto load_a = [&](int n, int stage) {
       const int tap = T0 + n / NR, rt = n % NR;
       const char* p = ldsb + tapoff[tap] + rt * PPT * 16;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) av[stage][pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
+      for (int pl = 0; pl < NPL; ++pl) av[stage][pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
     };
 #pragma unroll
     for (int n = 0; n < DIST && n < NT; ++n) load_a(n, n);
-    bf16x8 b[3];
+    bf16x8 b[NPL];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       if (n % NR == 0) {
         if constexpr (TRACE_BF3_WPF >= 2) {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
+          for (int p = 0; p < NPL; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
           ++sdone;
-          wp += 192;
+          wp += WSL;
           if (sdone + 1 < a.nsl) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bn2[p] = wp[192 + 64 * p];
+            for (int p = 0; p < NPL; ++p) bn2[p] = wp[WSL + 64 * p];
           }
         } else {
 #pragma unroll
-          for (int p = 0; p < 3; ++p) b[p] = bn1[p];
+          for (int p = 0; p < NPL; ++p) b[p] = bn1[p];
           ++sdone;
-          wp += 192;
+          wp += WSL;
 #ifndef TRACE_EXP_NOWLOAD
           if (sdone < a.nsl) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bn1[p] = wp[64 * p];
+            for (int p = 0; p < NPL; ++p) bn1[p] = wp[64 * p];
           }
 #endif
         }
@@ -352,12 +385,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
       }
       const int s = n % NST, rt = n % NR;
       f32x4 c = acc[rt];
+      if constexpr (SCH == 1) {
+        const f16x8 ah = __builtin_bit_cast(f16x8, av[s][0]), al = __builtin_bit_cast(f16x8, av[s][1]);
+        const f16x8 bh = __builtin_bit_cast(f16x8, b[0]), bl = __builtin_bit_cast(f16x8, b[1]);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, c, 0, 0, 0);
+      } else {
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][2], b[0], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[2], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][1], b[1], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][1], b[0], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[1], c, 0, 0, 0);
       c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[s][0], b[0], c, 0, 0, 0);
+      }
       acc[rt] = c;
       if constexpr (TRACE_BF3_PIN) __builtin_amdgcn_sched_barrier(0);
     }
@@ -421,6 +462,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   }
 
   if constexpr (TRACE_BF3_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+  if constexpr (SCH == 1) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] *= oscale;
+  }
 #ifndef TRACE_BF3_EPI_REGS
 #define TRACE_BF3_EPI_REGS 0      // forward GroupNorm / Mish on the accumulators (conv_epilogue_fwd_rows)
 #endif
@@ -441,7 +486,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw);
 }
 
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int NW = TRACE_BF3_NW,
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH = 0, int NW = TRACE_BF3_NW,
           int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4>
 int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW>;
@@ -453,7 +498,9 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   TRACE_REQUIRE((!a.outp || (a.outp_noct > 0 && (reinterpret_cast<uintptr_t>(a.outp) & 15) == 0)) &&
                     (!a.rawp || (a.rawp_noct > 0 && (reinterpret_cast<uintptr_t>(a.rawp) & 15) == 0)),
                 "conv(bf16x3): bad output plane tensor");
-  TRACE_REQUIRE(a.wb && a.cout % 64 == 0 && a.cin % 32 == 0 && a.cin2 % 32 == 0 &&
+  TRACE_REQUIRE(SCH == 0 || (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax) && a.wexp >= -10 && a.wexp <= 40),
+                "conv(fp16x2): weight stream, weight exponent or input amax missing");
+  TRACE_REQUIRE((SCH == 1 || a.wb) && a.cout % 64 == 0 && a.cin % 32 == 0 && a.cin2 % 32 == 0 &&
                     a.nsl == TAPS * a.cin / 32 + a.cin2 / 32,
                 "conv(bf16x3): bad channel geometry cin=%d cin2=%d cout=%d nsl=%d", a.cin, a.cin2, a.cout,
                 a.nsl);
@@ -489,7 +536,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   static unsigned long long attr_done = 0;      // one bit per device
   if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, NW, MINW>),
+        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   }
   const int nrb = (a.rows + TB - 1) / TB;
@@ -499,9 +546,9 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
 #endif
   const bool prof = prof_active();
   if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, NW, MINW>), grid, dim3(G::NTH), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW>), grid, dim3(G::NTH), lds_bytes, st, a);
   if (prof) prof_post(st, 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT);
-  return launch_status("conv_bf3_kernel");
+  return launch_status(SCH == 1 ? "conv_bf3_kernel(fp16x2)" : "conv_bf3_kernel");
 }
 
 // planes staging when the caller has the input's plane tensors (and, for a second K source, that one's too).
@@ -517,20 +564,27 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_ws(const ConvArgs& a_in, hipStream_t st);      // conv_ws_kernels.h
 int conv_ws_mode(int mode);                                    // unet.hip (trace_conv_ws_mode)
+int conv_scheme(int mode);                                     // unet.hip (trace_conv_scheme): 0 bf16 x 3, 1 fp16 x 2 where possible
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
-  if (a.inp && (a.cin2 == 0 || a.in2p)) return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, true>(a, st);
+  if (a.inp && (a.cin2 == 0 || a.in2p)) return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, true, 0>(a, st);
   const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
+  if (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax)) {          // every operand has its scale: the fp16 pipe
+    static const int small_max16 = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
+    if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max16)
+      return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
+    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1>(a, st);
+  }
   static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
   // full-chip launches of the multi-tap convs: the persistent wave-specialised kernel (conv_ws_kernels.h)
   if constexpr (TAPS > 1) {
-    if (conv_ws_mode(-1) && wgs > small_max && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp)
+    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > small_max && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp)
       return launch_conv_ws<L_OUT, UP, TAPS, PADL, TB>(a, st);
   }
   if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max)
-    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
-  return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false>(a, st);
+    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 0, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
+  return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 0>(a, st);
 }
 
 }  // namespace trace

@@ -99,6 +99,18 @@ struct ConvArgs {
   void* rawp;                // planes of `out_raw` to write (GroupNorm-backward epilogue), or null
   int rawp_noct, rawp_oct0;
   const void* zero_cell;     // 16 zero bytes in device memory: the source of halo / zero-stuffing cells
+  // Split-fp16 K loop (conv_bf3_kernels.h, SCH = 1): operands as TWO fp16 terms, three MFMAs per product.  fp16 has
+  // 5 exponent bits, so both operands are brought into range by exact powers of two: the weights on the host
+  // (wexp, per layer), the activations per group of 16 trajectories from the largest |value| their PRODUCER saw
+  // (amax arrays: one uint = fp32 bit pattern per 16 trajectories, atomically max-ed by the epilogues that write
+  // the tensor, zeroed once per pass).  A launch runs on the fp16 pipe only when wh and the amax of every input
+  // are given; the accumulators are scaled back before the epilogue.
+  const void* wh;            // split-fp16 weight stream [cout/16][nsl][2 planes][64 lanes] x 8 fp16 (scaled by 2^wexp), or null
+  int wexp;
+  const unsigned* in_amax;   // max |in| per 16 trajectories (index row / 16), or null
+  const unsigned* in2_amax;
+  unsigned* out_amax;        // where this launch's epilogue records max |out| (null: not recorded)
+  unsigned* raw_amax;        // ... and max |out_raw| of the GroupNorm-backward epilogue
 };
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -125,6 +137,66 @@ __device__ __forceinline__ void split8_bf16(const float (&v)[8], u32x4v& h, u32x
     m[i] = pm;
     l[i] = cvt_pk_bf16(s0, s1);
   }
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_f16(float lo, float hi) {
+  unsigned r;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  return r;
+}
+// a - float(low / high half of h): one mixed-precision FMA (exact: h is a rounded to 11 bits)
+__device__ __forceinline__ float sub_f16_lo(float a, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(h));
+  return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float a, unsigned h) {
+  float r;
+  asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(a), "v"(h));
+  return r;
+}
+// 8 fp32 values, times the power of two s -> two fp16 planes: v s = h + l up to 2^-24 |v s| (l keeps 11 of the 13
+// bits h leaves; below |v s| = 2^-3 the low term is subnormal and the absolute error stays at 2^-25)
+__device__ __forceinline__ void split8_f16(const float (&v)[8], const float s, u32x4v& h, u32x4v& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float a0 = v[2 * i] * s, a1 = v[2 * i + 1] * s;
+    const unsigned ph = cvt_pk_f16(a0, a1);
+    h[i] = ph;
+    l[i] = cvt_pk_f16(sub_f16_lo(a0, ph), sub_f16_hi(a1, ph));
+  }
+}
+
+// max over the wave on DPP modifiers (16-lane rows) + v_readlane across rows; v >= 0
+__device__ __forceinline__ float wave_max_nonneg(float v) {
+  auto step = [](float x, int tag) {
+    const int xi = __builtin_bit_cast(int, x);
+    int y;
+    switch (tag) {
+      case 1: y = __builtin_amdgcn_update_dpp(0, xi, 0xB1, 0xF, 0xF, false); break;
+      case 2: y = __builtin_amdgcn_update_dpp(0, xi, 0x4E, 0xF, 0xF, false); break;
+      case 4: y = __builtin_amdgcn_update_dpp(0, xi, 0x141, 0xF, 0xF, false); break;
+      default: y = __builtin_amdgcn_update_dpp(0, xi, 0x140, 0xF, 0xF, false); break;
+    }
+    return fmaxf(x, __builtin_bit_cast(float, y));
+  };
+  v = step(v, 1); v = step(v, 2); v = step(v, 4); v = step(v, 8);
+  const int x = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(x, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// the workgroup's trajectories (at most 16, aligned) share one amax slot
+__device__ __forceinline__ void record_amax(unsigned* amax, const int traj0, float m) {
+  m = wave_max_nonneg(m);
+  if ((threadIdx.x & 63) == 0) atomicMax(amax + (traj0 >> 4), __builtin_bit_cast(unsigned, m));
+}
+__device__ __forceinline__ float amax4(float m, const f32x4 y) {
+  return fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
 }
 
 // The finished 64-channel output tile in LDS ([trajectory][channel][position] fp32) -> plane cells in HBM.
@@ -349,6 +421,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         a.out_raw ? a.out_raw : a.out, 0,
         a.out_raw ? (unsigned)((size_t)a.rows * a.raw_tstride * sizeof(float)) : 0u, 0x00020000);
+    float mraw = 0.f;
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       float* cell = lds_cell(k);
@@ -356,11 +429,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
       y += rv[k];
       if (a.out_raw) {
         int rem;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rw,
-                                               flat_off(k, a.raw_tstride, a.raw_coff, rem), 0, 0);
+        const unsigned oo = flat_off(k, a.raw_tstride, a.raw_coff, rem);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rw, oo, 0, 0);
+        if (oo != 0xffffffffu) mraw = amax4(mraw, y);
       }
       if (flat_live(k)) *reinterpret_cast<f32x4*>(cell) = y;
     }
+    if (a.raw_amax && a.out_raw) record_amax(a.raw_amax, traj0, mraw);
     if (!normed) {                             // uniform per workgroup
       if (a.rawp) {
         __syncthreads();
@@ -453,13 +528,16 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     // G3 (flat): d/dy out
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
         a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
+    float mout = 0.f;
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       const f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
       int rem;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro,
-                                             flat_off(k, a.out_tstride, a.out_coff, rem), 0, 0);
+      const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
+      if (oo != 0xffffffffu) mout = amax4(mout, y);
     }
+    if (a.out_amax) record_amax(a.out_amax, traj0, mout);
     if (a.outp)                                // the tile still holds d/dy
       write_planes<L_OUT, TB, NTH>(lds, a.outp, a.outp_noct, a.outp_oct0 + (co0 >> 3), traj0, a.rows);
     TRACE_STAMP(11);
@@ -603,6 +681,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
   // E2: flat pass -- + residual(s), store; 4 consecutive outputs per access
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
       a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
+  float mout = 0.f;
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
@@ -610,8 +689,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
     y += rv[k];
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
+    if (oo != 0xffffffffu) mout = amax4(mout, y);
     if (a.outp && flat_live(k)) *reinterpret_cast<f32x4*>(lds_cell(k)) = y;      // the finished value, for the planes
   }
+  if (a.out_amax) record_amax(a.out_amax, traj0, mout);
   if (a.outp) {
     __syncthreads();
     write_planes<L_OUT, TB, NTH>(lds, a.outp, a.outp_noct, a.outp_oct0 + (co0 >> 3), traj0, a.rows);

@@ -23,6 +23,21 @@ int conv_ws_mode(int mode) {
   return prev;
 }
 
+// Operand scheme of the implicit-GEMM convs: 1 (default) = two fp16 terms / three MFMAs per product wherever a
+// launch has the scales of all its operands (conv_bf3_kernels.h, SCH = 1), 0 = three bf16 terms / six MFMAs
+// everywhere.  TRACE_CONV_SCHEME=bf16x3 | fp16x2 presets it; returns the previous value.
+int conv_scheme(int mode) {
+  static int cur = -1;
+  int prev = __atomic_load_n(&cur, __ATOMIC_ACQUIRE);
+  if (prev < 0) {
+    const char* e = getenv("TRACE_CONV_SCHEME");
+    prev = e ? (strcmp(e, "bf16x3") == 0 || strcmp(e, "0") == 0 ? 0 : 1) : 1;
+    __atomic_store_n(&cur, prev, __ATOMIC_RELEASE);
+  }
+  if (mode >= 0) __atomic_store_n(&cur, mode != 0, __ATOMIC_RELEASE);
+  return prev;
+}
+
 int conv_ws_num_cus() {
   static int cus[64] = {0};
   int dev = 0;
@@ -97,7 +112,8 @@ __global__ __launch_bounds__(64) void gn_mish_bwd_kernel(const float* __restrict
                                                           const float* __restrict__ beta,
                                                           float* __restrict__ dy, int C, int cg,
                                                           int rows, const float* __restrict__ head_g,
-                                                          const float* __restrict__ head_w) {
+                                                          const float* __restrict__ head_w,
+                                                          float* __restrict__ gscale) {
   const int ngroups = C / cg;
   const int row = blockIdx.x / ngroups;
   const int g = blockIdx.x - row * ngroups;
@@ -109,6 +125,24 @@ __global__ __launch_bounds__(64) void gn_mish_bwd_kernel(const float* __restrict
   const float* yb = y + ((size_t)row * C + g * cg) * L;
   const float* db = da + (size_t)row * da_tstride + (size_t)(da_coff + g * cg) * L;
   float* ob = dy + ((size_t)row * C + g * cg) * L;
+  // The input-VJP is linear in each trajectory's incoming gradient.  With `gscale` the head brings every
+  // trajectory's gradient to a largest |entry| in [1, 2) by an exact power of two (recorded in gscale[row] and
+  // multiplied back by first_dgrad_kernel), so that trajectories whose guidance gradients differ by many orders
+  // of magnitude share the per-16-trajectory operand scales of the fp16 convs (conv_bf3_kernels.h, SCH = 1).
+  float hs = 1.f;
+  if (head_g && gscale) {
+    float m = 0.f;
+    for (int e = lane; e < 2 * L; e += 64) m = fmaxf(m, fabsf(head_g[(size_t)row * L * 2 + e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    int ef = (int)(__builtin_bit_cast(unsigned, m) >> 23);
+    if (ef >= 1 && ef <= 253) {                       // zero / subnormal / non-finite rows stay as they are
+      hs = __builtin_bit_cast(float, (unsigned)(254 - ef) << 23);          // 2^-E
+      if (g == 0 && lane == 0) gscale[row] = __builtin_bit_cast(float, (unsigned)ef << 23);
+    } else if (g == 0 && lane == 0) {
+      gscale[row] = 1.f;
+    }
+  }
   constexpr int MAXE = 7;
   float gg[MAXE], xh[MAXE];
   float s1 = 0.f, s2 = 0.f;
@@ -128,7 +162,7 @@ __global__ __launch_bounds__(64) void gn_mish_bwd_kernel(const float* __restrict
       if (head_g) {
         const int t = e - c * L;
         const float* gp = head_g + ((size_t)row * L + t) * 2;
-        up = head_w[g * cg + c] * gp[0] + head_w[C + g * cg + c] * gp[1];
+        up = head_w[g * cg + c] * (gp[0] * hs) + head_w[C + g * cg + c] * (gp[1] * hs);
       } else {
         up = db[e];
       }
@@ -186,11 +220,13 @@ __global__ __launch_bounds__(256) void first_dgrad_kernel(const float* __restric
                                                           const float* __restrict__ dout,
                                                           const float* __restrict__ wsel,
                                                           const float* __restrict__ rsel,
-                                                          float* __restrict__ gx, int C, int L, int rows) {
+                                                          float* __restrict__ gx, int C, int L, int rows,
+                                                          const float* __restrict__ gscale) {
   const int nq = L >> 2;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= rows * nq) return;
   const int row = idx / nq, q = idx - row * nq, t0 = q * 4;
+  const float gs = gscale ? gscale[row] : 1.f;         // undo the head's per-trajectory power of two
   const float* yb = dy1 + (size_t)row * C * L + t0;
   const float* ob = dout + (size_t)row * C * L + t0;
   float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -216,8 +252,8 @@ __global__ __launch_bounds__(256) void first_dgrad_kernel(const float* __restric
     }
   }
   f32x4* out = reinterpret_cast<f32x4*>(gx + ((size_t)row * L + t0) * 2);
-  out[0] = f32x4{a0[0], a1[0], a0[1], a1[1]};
-  out[1] = f32x4{a0[2], a1[2], a0[3], a1[3]};
+  out[0] = f32x4{a0[0] * gs, a1[0] * gs, a0[1] * gs, a1[1] * gs};
+  out[1] = f32x4{a0[2] * gs, a1[2] * gs, a0[3] * gs, a1[3] * gs};
 }
 
 // table[r][j] = bias[j] + sum_k W[j][k] mish(cond[r][k])
@@ -257,6 +293,8 @@ struct PackedConv {
   void* wb = nullptr;  // device, split-bf16 stream [cout/16][nsl][3][64] x 8 bf16 (null: fp32 kernel only)
   int nsl = 0;
   int cin_b = 0;       // input channels of that stream: cin_real rounded up to 32 (zero weights)
+  void* wh = nullptr;  // device, split-fp16 stream [cout/16][nsl][2][64] x 8 fp16 of the weights times 2^wexp
+  int wexp = 0;        // the layer's largest |weight| times 2^wexp lies in [2^13, 2^14)
 };
 
 struct Block {
@@ -422,6 +460,52 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
     pc->wb = db;
     pc->nsl = nsl;
     pc->cin_b = cin_b;
+    // split-fp16 stream, same slice order: w 2^wexp = h + l, both fp16 (round-to-nearest), wexp from the layer's
+    // largest |w| so that every low term of a weight within 2^-10 of it is a normal fp16
+    float wmax = 0.f;
+    for (int co = 0; co < cout; ++co) {
+      for (int ci = 0; ci < cin_real; ++ci)
+        for (int tap = 0; tap < taps; ++tap) wmax = fmaxf(wmax, fabsf(get(tap, ci, co)));
+      for (int ci = 0; ci < cin2; ++ci) wmax = fmaxf(wmax, fabsf(get2(ci, co)));
+    }
+    int wexp = 0;
+    if (wmax > 0.f && std::isfinite(wmax)) {
+      int e;
+      frexpf(wmax, &e);                // wmax in [2^(e-1), 2^e)
+      wexp = 14 - e;
+    }
+    wexp = wexp < -10 ? -10 : (wexp > 40 ? 40 : wexp);
+    std::vector<uint16_t> hh((size_t)(cout / 16) * nsl * 2 * 64 * 8, 0);
+    auto f16_bits = [](float v) -> uint16_t {
+      const _Float16 h = (_Float16)v;
+      uint16_t b;
+      memcpy(&b, &h, 2);
+      return b;
+    };
+    for (int ct = 0; ct < cout / 16; ++ct) {
+      int sl = 0;
+      auto put = [&](int c0, int tap, bool second) {
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 8; ++j) {
+            const int ci = c0 + (lane >> 4) * 8 + j;
+            const int co = ct * 16 + (lane & 15);
+            const float v = ldexpf(second ? get2(ci, co) : (ci < cin_real ? get(tap, ci, co) : 0.f), wexp);
+            const _Float16 h = (_Float16)v;
+            const size_t base = (((size_t)ct * nsl + sl) * 2 * 64 + lane) * 8 + j;
+            hh[base] = f16_bits((float)h);
+            hh[base + 64 * 8] = f16_bits(v - (float)h);
+          }
+        ++sl;
+      };
+      for (int c0 = 0; c0 < cin_b; c0 += 32)
+        for (int tap = 0; tap < taps; ++tap) put(c0, tap, false);
+      for (int c0 = 0; c0 < cin2; c0 += 32) put(c0, 0, true);
+    }
+    uint16_t* dh = nullptr;
+    rc = upload(u, hh, &dh);
+    if (rc) return rc;
+    pc->wh = dh;
+    pc->wexp = wexp;
   }
   return TRACE_OK;
 }
@@ -754,7 +838,11 @@ namespace {
 struct Layout {
   std::vector<int64_t> off;  // float offsets
   int64_t total = 0;
+  int64_t amax_off = 0;      // the amax arrays (ConvArgs::in_amax ...): AMAX_SLOTS x ngroups uints
+  int ngroups = 0;           // groups of 16 trajectories
+  int64_t gscale_off = 0;    // per-trajectory power of two of the incoming gradient (input-VJP), rows floats
 };
+constexpr int AMAX_SLOTS = 160;   // forward: one per buffer id; backward: one per produced tensor
 
 Layout make_layout(const trace_unet* u, int rows, int save) {
   Layout l;
@@ -766,6 +854,11 @@ Layout make_layout(const trace_unet* u, int rows, int save) {
     int64_t n = (int64_t)u->buf_floats[i] * rows;
     o += (n + 63) / 64 * 64;
   }
+  l.ngroups = (rows + 15) / 16;
+  l.amax_off = o;
+  o += ((int64_t)AMAX_SLOTS * l.ngroups + 63) / 64 * 64;
+  l.gscale_off = o;
+  o += ((int64_t)rows + 63) / 64 * 64;
   l.total = o;
   return l;
 }
@@ -777,6 +870,11 @@ thread_local const void* t_zero_cell = nullptr;     // set by trace_unet_forward
 int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
   a.zero_cell = t_zero_cell;
+  if (!conv_scheme(-1)) {                    // bf16 x 3 everywhere, nothing recorded
+    a.wh = nullptr;
+    a.in_amax = a.in2_amax = nullptr;
+    a.out_amax = a.raw_amax = nullptr;
+  }
   // zero-stuffed (transposed) convolutions multiply half of their taps by structural zeros
   if (kind == K_UP_F || kind == K_DOWN_B) a.alg_macs_per_pos *= 0.5;
   const int ch = a.chunk;
@@ -860,9 +958,10 @@ struct View {
   int coff;
   int L;
   void* pl = nullptr;     // pre-split bf16 planes of the same (ctot, L) tensor, or null
+  unsigned* amax = nullptr;   // max |value| per 16 trajectories, recorded by the tensor's producer(s), or null
   int tstride() const { return ctot * L; }
-  View sub(int c0) const { return View{p, ctot, coff + c0, L, pl}; }
-  View no_planes() const { return View{p, ctot, coff, L, nullptr}; }
+  View sub(int c0) const { return View{p, ctot, coff + c0, L, pl, amax}; }
+  View no_planes() const { return View{p, ctot, coff, L, nullptr, amax}; }
 };
 
 ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const View& out,
@@ -886,6 +985,10 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.wb = w.wb;
   a.nsl = w.nsl;
   a.cin_b = w.cin_b;
+  a.wh = w.wh;
+  a.wexp = w.wexp;
+  a.in_amax = in.amax;
+  a.out_amax = out.amax;
   if (in.pl && in.coff % 8 == 0 && in.ctot % 8 == 0) {
     a.inp = in.pl;
     a.inp_noct = in.ctot / 8;
@@ -903,6 +1006,7 @@ void set_in2(ConvArgs& a, const View& v) {
   a.in2 = v.p;
   a.in2_tstride = v.tstride();
   a.in2_coff = v.coff;
+  a.in2_amax = v.amax;
   if (v.pl && v.coff % 8 == 0 && v.ctot % 8 == 0) {
     a.in2p = v.pl;
     a.in2p_noct = v.ctot / 8;
@@ -927,6 +1031,7 @@ void set_gnb(ConvArgs& a, const float* y, const float* stats, const float* gamma
     a.out_raw = raw->p;
     a.raw_tstride = raw->tstride();
     a.raw_coff = raw->coff;
+    a.raw_amax = raw->amax;
     if (raw->pl && raw->coff % 8 == 0 && raw->ctot % 8 == 0) {
       a.rawp = raw->pl;
       a.rawp_noct = raw->ctot / 8;
@@ -934,7 +1039,9 @@ void set_gnb(ConvArgs& a, const float* y, const float* stats, const float* gamma
     }
   } else {
     a.out_raw = nullptr;
+    a.raw_amax = nullptr;
   }
+  a.out_amax = dy.amax;
   a.out = dy.p;
   a.out_tstride = dy.tstride();
   a.out_coff = dy.coff;
@@ -959,12 +1066,12 @@ void set_res2(ConvArgs& a, const View& r) {
 
 int run_gn_bwd(const View& da, const float* y, const float* stats, const float* gamma,
                const float* beta, float* dy, int C, int L, int rows, hipStream_t st,
-               const float* head_g = nullptr, const float* head_w = nullptr) {
+               const float* head_g = nullptr, const float* head_w = nullptr, float* gscale = nullptr) {
   int cg = C / 8;
   dim3 grid(rows * 8);
 #define GNB(LL)                                                                              \
   hipLaunchKernelGGL(gn_mish_bwd_kernel<LL>, grid, dim3(64), 0, st, da.p, da.tstride(), da.coff, \
-                     y, stats, gamma, beta, dy, C, cg, rows, head_g, head_w)
+                     y, stats, gamma, beta, dy, C, cg, rows, head_g, head_w, gscale)
   if (L == 52) GNB(52);
   else if (L == 26) GNB(26);
   else if (L == 13) GNB(13);
@@ -1014,9 +1121,13 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in, const float*
   // views of each block's input / output (skip concatenation is done by writing in place)
   t_zero_cell = u->zero_cell;
   // a buffer with its plane twin (the twin is written by the producing conv's epilogue)
+  TRACE_REQUIRE((int)u->buf_floats.size() <= AMAX_SLOTS, "amax slots: %d buffers", (int)u->buf_floats.size());
+  unsigned* const amax_base = reinterpret_cast<unsigned*>(ws + lay.amax_off);
+  TRACE_CHECK_HIP(hipMemsetAsync(amax_base, 0, (size_t)AMAX_SLOTS * lay.ngroups * sizeof(unsigned), st));
   auto whole = [&](int id, int C, int L) {
     const int tw = id >= 0 ? u->buf_twin[id] : -1;
-    return View{buf(id), C, 0, L, tw >= 0 ? (void*)buf(tw) : nullptr};
+    return View{buf(id), C, 0, L, tw >= 0 ? (void*)buf(tw) : nullptr,
+                id >= 0 ? amax_base + (size_t)id * lay.ngroups : nullptr};
   };
   std::vector<View> bin(u->nblocks), bout(u->nblocks);
   const int d0 = c.dims[0], d1 = c.dims[1], d2 = c.dims[2];
@@ -1116,12 +1227,24 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
   t_zero_cell = u->zero_cell;
   // views of the gradient scratch buffers with their plane twins; the same buffer is reused with different
   // (channels, length) shapes, which is consistent as long as a tensor's producer and consumers agree
+  // amax slots: the gradient buffers are rewritten many times with different tensors, so every PRODUCED tensor
+  // takes a fresh slot (`produced`), and later views of the buffer carry the slot of its latest producer
+  unsigned* const amax_base = reinterpret_cast<unsigned*>(ws + lay.amax_off);
+  TRACE_CHECK_HIP(hipMemsetAsync(amax_base, 0, (size_t)AMAX_SLOTS * lay.ngroups * sizeof(unsigned), st));
+  float* const gscale = conv_scheme(-1) ? ws + lay.gscale_off : nullptr;     // fp16 scheme only: scheme 0 is untouched
+  std::vector<int> slot_of(u->buf_floats.size(), -1);
+  int next_slot = 0;
   auto view = [&](int id, int C, int coff, int L) {
     const int tw = u->buf_twin[id];
-    return View{buf(id), C, coff, L, tw >= 0 ? (void*)buf(tw) : nullptr};
+    return View{buf(id), C, coff, L, tw >= 0 ? (void*)buf(tw) : nullptr,
+                slot_of[id] >= 0 ? amax_base + (size_t)slot_of[id] * lay.ngroups : nullptr};
+  };
+  auto produced = [&](int id, int C, int coff, int L) {
+    slot_of[id] = next_slot < AMAX_SLOTS ? next_slot++ : -1;       // out of slots: consumers fall back to bf16 x 3
+    return view(id, C, coff, L);
   };
   const int iT1 = u->b_T1, iT2 = u->b_T2, iG0 = u->b_G0, iG1 = u->b_G1;
-  View dcat1 = view(u->b_dcat1, 2 * d1, 0, H / 2), dcat2 = view(u->b_dcat2, 2 * d2, 0, H / 4);
+  View dcat1 = produced(u->b_dcat1, 2 * d1, 0, H / 2), dcat2 = produced(u->b_dcat2, 2 * d2, 0, H / 4);
 
   // GroupNorm+Mish backward is fused into the epilogue of whichever dgrad conv PRODUCES the
   // gradient (set_gnb); only the very first one (after the head) runs as its own kernel.
@@ -1133,7 +1256,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
   //   dx = dgrad_c1(T2) [+ dgrad_res(dout) as extra K | + dout] [+ extra];  T1 = gnb(dx; y2_next)
   auto block_bwd = [&](int i, const View& dout, const View& dx, const View* extra, int next) -> int {
     const Block& b = u->blocks[i];
-    View t1 = view(iT1, b.cout, 0, b.L), t2 = view(iT2, b.cout, 0, b.L);
+    View t1 = view(iT1, b.cout, 0, b.L), t2 = produced(iT2, b.cout, 0, b.L);
     {
       ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
       set_gnb(a, buf(u->b_y1[i]), buf(u->b_s1[i]), b.g1, b.be1, b.cout, t2, nullptr);
@@ -1144,7 +1267,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
     if (extra) set_res2(a, *extra);
     if (next >= 0) {
       const Block& nb = u->blocks[next];
-      View nt1 = view(iT1, nb.cout, 0, nb.L);
+      View nt1 = produced(iT1, nb.cout, 0, nb.L);
       set_gnb(a, buf(u->b_y2[next]), buf(u->b_s2[next]), nb.g2, nb.be2, nb.cout, nt1, &dx);
     }
     RUN(run_conv(K_CONV5, b.L, a, st));
@@ -1156,69 +1279,72 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
     ConvArgs a = conv_args(in, w, nullptr, dx, rows);
     if (res) set_res(a, *res);
     const Block& nb = u->blocks[next];
-    View nt1 = view(iT1, nb.cout, 0, nb.L);
+    View nt1 = produced(iT1, nb.cout, 0, nb.L);
     set_gnb(a, buf(u->b_y2[next]), buf(u->b_s2[next]), nb.g2, nb.be2, nb.cout, nt1, &dx);
     return run_conv(kind, L_out, a, st);
   };
 
   // head + final block
   {
-    View g0 = view(iG0, d0, 0, H), g1 = view(iG1, d0, 0, H);
-    View t1 = view(iT1, d0, 0, H).no_planes();          // written by gn_mish_bwd_kernel: fp32 only
-    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, t1.p, d0, H, rows, st, grad_pred, u->head_w));
+    View g0 = view(iG0, d0, 0, H), g1 = produced(iG1, d0, 0, H);
+    View t1 = view(iT1, d0, 0, H).no_planes();          // written by gn_mish_bwd_kernel: fp32 only, no amax
+    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, t1.p, d0, H, rows, st, grad_pred, u->head_w, gscale));
     RUN(run_conv(K_CONV5, H, conv_args(t1, u->final_b, nullptr, g1, rows), st));
   }
   // up1 (ConvT d0: L/2 -> L): its dgrad output is dout of block 11
-  RUN(resample_bwd(K_UP_B, H / 2, view(iG1, d0, 0, H), u->up_b[1], view(iG0, d0, 0, H / 2), nullptr, 11));
-  RUN(block_bwd(11, view(iG0, d0, 0, H / 2), view(iG1, d0, 0, H / 2), nullptr, 10));
+  // (every call's operands: views of what exists first, then the `produced` view of what the call writes)
+  { View in = view(iG1, d0, 0, H); RUN(resample_bwd(K_UP_B, H / 2, in, u->up_b[1], produced(iG0, d0, 0, H / 2), nullptr, 11)); }
+  { View in = view(iG0, d0, 0, H / 2); RUN(block_bwd(11, in, produced(iG1, d0, 0, H / 2), nullptr, 10)); }
   RUN(block_bwd(10, view(iG1, d0, 0, H / 2), dcat1, nullptr, -1));
   // up0 (ConvT d1: L/4 -> L/2) reads the first half of dcat1; output = dout of block 9
-  RUN(resample_bwd(K_UP_B, H / 4, dcat1.sub(0), u->up_b[0], view(iG0, d1, 0, H / 4), nullptr, 9));
-  RUN(block_bwd(9, view(iG0, d1, 0, H / 4), view(iG1, d1, 0, H / 4), nullptr, 8));
+  RUN(resample_bwd(K_UP_B, H / 4, dcat1.sub(0), u->up_b[0], produced(iG0, d1, 0, H / 4), nullptr, 9));
+  { View in = view(iG0, d1, 0, H / 4); RUN(block_bwd(9, in, produced(iG1, d1, 0, H / 4), nullptr, 8)); }
   // block 8 writes dcat2 (2*d2 channels); only its first half is dout of mid2 (block 7)
   {
     const Block& b = u->blocks[8];
-    View t1 = view(iT1, b.cout, 0, b.L), t2 = view(iT2, b.cout, 0, b.L);
+    View t1 = view(iT1, b.cout, 0, b.L), t2 = produced(iT2, b.cout, 0, b.L);
     ConvArgs a2 = conv_args(t1, b.c2b, nullptr, t2, rows);
     set_gnb(a2, buf(u->b_y1[8]), buf(u->b_s1[8]), b.g1, b.be1, b.cout, t2, nullptr);
     RUN(run_conv(K_CONV5, b.L, a2, st));
     ConvArgs a = conv_args(t2, b.c1b, nullptr, dcat2, rows);
     set_in2(a, view(iG1, d1, 0, H / 4));
     const Block& nb = u->blocks[7];
-    View nt1 = view(iT1, nb.cout, 0, nb.L);
+    View nt1 = produced(iT1, nb.cout, 0, nb.L);
     set_gnb(a, buf(u->b_y2[7]), buf(u->b_s2[7]), nb.g2, nb.be2, nb.cout, nt1, &dcat2);
     RUN(run_conv(K_CONV5, b.L, a, st));
   }
   // mid2: dout = dcat2[0:d2]
-  RUN(block_bwd(7, dcat2.sub(0), view(iG0, d2, 0, H / 4), nullptr, 6));
+  RUN(block_bwd(7, dcat2.sub(0), produced(iG0, d2, 0, H / 4), nullptr, 6));
   // mid1: + skip gradient dcat2[d2:2*d2]
   {
     View skip = dcat2.sub(d2);
-    RUN(block_bwd(6, view(iG0, d2, 0, H / 4), view(iG1, d2, 0, H / 4), &skip, 5));
+    View in = view(iG0, d2, 0, H / 4);
+    RUN(block_bwd(6, in, produced(iG1, d2, 0, H / 4), &skip, 5));
   }
-  RUN(block_bwd(5, view(iG1, d2, 0, H / 4), view(iG0, d2, 0, H / 4), nullptr, 4));
-  RUN(block_bwd(4, view(iG0, d2, 0, H / 4), view(iG1, d1, 0, H / 4), nullptr, -1));
+  { View in = view(iG1, d2, 0, H / 4); RUN(block_bwd(5, in, produced(iG0, d2, 0, H / 4), nullptr, 4)); }
+  { View in = view(iG0, d2, 0, H / 4); RUN(block_bwd(4, in, produced(iG1, d1, 0, H / 4), nullptr, -1)); }
   // down1 (Conv k3 s2 d1: L/2 -> L/4) + skip gradient dcat1[d1:2*d1]; output = dout of block 3
   {
     View skip = dcat1.sub(d1);
-    RUN(resample_bwd(K_DOWN_B, H / 2, view(iG1, d1, 0, H / 4), u->down_b[1], view(iG0, d1, 0, H / 2), &skip, 3));
+    View in = view(iG1, d1, 0, H / 4);
+    RUN(resample_bwd(K_DOWN_B, H / 2, in, u->down_b[1], produced(iG0, d1, 0, H / 2), &skip, 3));
   }
-  RUN(block_bwd(3, view(iG0, d1, 0, H / 2), view(iG1, d1, 0, H / 2), nullptr, 2));
-  RUN(block_bwd(2, view(iG1, d1, 0, H / 2), view(iG0, d0, 0, H / 2), nullptr, -1));
+  { View in = view(iG0, d1, 0, H / 2); RUN(block_bwd(3, in, produced(iG1, d1, 0, H / 2), nullptr, 2)); }
+  { View in = view(iG1, d1, 0, H / 2); RUN(block_bwd(2, in, produced(iG0, d0, 0, H / 2), nullptr, -1)); }
   // down0 (Conv k3 s2 d0: L -> L/2); the level-0 skip is never consumed (temporal.py:129,134)
-  RUN(resample_bwd(K_DOWN_B, H, view(iG0, d0, 0, H / 2), u->down_b[0], view(iG1, d0, 0, H), nullptr, 1));
-  RUN(block_bwd(1, view(iG1, d0, 0, H), view(iG0, d0, 0, H), nullptr, 0));
+  { View in = view(iG0, d0, 0, H / 2); RUN(resample_bwd(K_DOWN_B, H, in, u->down_b[0], produced(iG1, d0, 0, H), nullptr, 1)); }
+  { View in = view(iG1, d0, 0, H); RUN(block_bwd(1, in, produced(iG0, d0, 0, H), nullptr, 0)); }
   // first block: only input channels [4,5] are needed (tbsim/models/trace.py:674-676)
   {
     const Block& b = u->blocks[0];
-    View t1 = view(iT1, d0, 0, H), t2 = view(iT2, d0, 0, H).no_planes();      // t2 feeds first_dgrad_kernel (fp32)
+    View t1 = view(iT1, d0, 0, H), t2 = produced(iT2, d0, 0, H).no_planes();      // t2 feeds first_dgrad_kernel (fp32)
     ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
     set_gnb(a, buf(u->b_y1[0]), buf(u->b_s1[0]), b.g1, b.be1, b.cout, t2, nullptr);
     RUN(run_conv(K_CONV5, b.L, a, st));
     TRACE_REQUIRE(H % 4 == 0, "first_dgrad: horizon %d not a multiple of 4", H);
     int n = rows * (H / 4);
     hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t2.p, buf(iG0),
-                       u->first_wsel, u->first_rsel, grad_x, d0, H, rows);
+                       u->first_wsel, u->first_rsel, grad_x, d0, H, rows, gscale);
     RUN(launch_status("first_dgrad_kernel"));
   }
   return TRACE_OK;
@@ -1226,6 +1352,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
 
 // ---- profiling entry points ---------------------------------------------------------------
 extern "C" int trace_conv_ws_mode(int mode) { return trace::conv_ws_mode(mode); }
+extern "C" int trace_conv_scheme(int mode) { return trace::conv_scheme(mode); }
 
 extern "C" int trace_profile_begin(int max_launches) {
   TRACE_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), "trace_profile_begin: bad size");
