@@ -170,11 +170,15 @@ def conv_roofline(model, batch, N, wl, gen, device, n_prof_steps=5):
     share = min(ms.value / t_b, 1.0) if t_b > 0 else 0.0
     conv_ms = share * t_a                               # conv time of the undisturbed pass
     achieved = fl.value / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # The conv kernel computes fp32 results on the bf16 matrix pipe: every algorithmic multiply-add
-    # is 6 bf16 MFMA multiply-adds (exact 3-way operand split), so its MFMA
-    # roof in ALGORITHMIC FLOP/s is the dense bf16 peak / 6.  `achieved` counts algorithmic FLOPs.
-    bf16_peak, fp32_mfma_peak = 2500.0, 157.3
-    peak = bf16_peak / 6.0
+    # The conv kernels compute fp32 results on the 16-bit matrix pipe from exactly split operands (DESIGN.md
+    # section 5.1): a launch on the fp16-pair scheme issues 3 MFMA multiply-adds per algorithmic one, a launch on the
+    # bf16-triple scheme 6, the four stride-2 launches still run the fp32 MFMA.  The library adds up each launch's
+    # matrix-pipe time at the dense peak (trace_profile_pipe_seconds); frac = that time / the measured conv time,
+    # and `peak` is the rate this mix of launches would reach with the pipe always busy (achieved / frac).
+    pipe_ms = float(L.trace_profile_pipe_seconds()) * 1e3
+    frac = pipe_ms / conv_ms if conv_ms > 0 else 0.0
+    peak = achieved / frac if frac > 0 else 0.0
+    mfma16_peak, fp32_mfma_peak = 2500.0, 157.3
     # HBM bytes per launch cannot be counted from inside this process: the value comes from the
     # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (profiles/, corrected as
     # MI355X_MICROARCH.md prescribes), null when that summary is absent.
@@ -183,14 +187,20 @@ def conv_roofline(model, batch, N, wl, gen, device, n_prof_steps=5):
     if os.path.exists(tpath):
         with open(tpath) as f:
             traffic = float(json.load(f)["hbm_bytes_per_launch"])
+    scheme = "fp16x2" if int(L.trace_conv_scheme(-1)) else "bf16x3"
     return {"bound": "mfma",
-            "kernel": "conv_bf3_kernel (fp32 implicit-GEMM conv as 6 bf16-MFMA terms per product, fp32 accumulate)",
-            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "peak_is": "dense bf16 MFMA peak 2500 TFLOP/s / 6 MFMA terms per algorithmic product",
+            "kernel": "conv_bf3_kernel (fp32 implicit-GEMM conv from exactly split operands, fp32 accumulate; "
+                      "scheme %s: %s MFMA terms per product)" % (scheme, "3 fp16" if scheme == "fp16x2" else "6 bf16"),
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": frac,
+            "peak_is": "algorithmic FLOP/s of this launch mix with the matrix pipe always busy: sum of the launches' "
+                       "algorithmic FLOPs / sum of their MFMA FLOPs (x3 fp16-pair, x6 bf16-triple) at the dense "
+                       "16-bit MFMA peak of 2500 TFLOP/s (fp32-MFMA launches at 157.3)",
+            "frac_of_bf16x6_roof": achieved / (mfma16_peak / 6.0),
             "frac_of_fp32_mfma_peak": achieved / fp32_mfma_peak,
             "traffic": traffic, "launches": int(nl.value),
             "avg_launch_us": conv_ms * 1e3 / max(nl.value, 1),
             "conv_ms_per_ddpm_step": conv_ms / n_prof_steps,
+            "pipe_ms_at_peak_per_ddpm_step": pipe_ms / n_prof_steps,
             "ddpm_step_ms": t_a / n_prof_steps,
             "conv_share_of_step": share,
             "per_launch_event_pass": {"sum_conv_ms": ms.value, "pass_ms": t_b}}
@@ -455,9 +465,10 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 results everywhere; the denoiser GEMMs evaluate each fp32 product as an exact 3-way "
-                          "bf16 operand split (6 bf16-MFMA terms, fp32 accumulate; rms error equal to the fp32 "
-                          "MFMA's, DESIGN.md section 5.1)",
+            "dtype_note": "fp32 results everywhere; the denoiser GEMMs evaluate each fp32 product from exactly split "
+                          "operands on the 16-bit matrix pipe with fp32 accumulation: two fp16 terms with "
+                          "power-of-two operand scales (3 MFMA terms; rms error vs fp64 3.6e-7 at K=1280, the fp32 "
+                          "MFMA's is 5.8e-7) or three bf16 terms (6 MFMA terms, 5.3e-7) -- DESIGN.md section 5.1",
             "data": "synthetic (seeded ORCA-style scenes, random-init orca_mixed weights)"
                     + ("; inputs in HOST memory, PCIe copy inside the timed region" if args.host_inputs else ""),
             "config": {"workload": args.workload, "agents_per_gpu": B, "samples_per_agent": N,

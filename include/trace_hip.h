@@ -103,6 +103,11 @@ int trace_unet_backward_input(trace_unet* u, const float* grad_pred, int rows, f
  * bench.py for the roofline figures. */
 int trace_profile_begin(int max_launches);
 int trace_profile_end(double* total_ms, int64_t* launches, double* total_flops);
+/* Matrix-pipe time of the profile trace_profile_end last closed, had every conv launch run at the chip's dense
+ * MFMA peak: sum over launches of (algorithmic FLOPs x MFMA terms per product: 3 for the fp16-pair scheme, 6 for
+ * the bf16-triple scheme) / 2500 TFLOP/s, or FLOPs / 157.3 TFLOP/s for launches on the fp32 MFMA.  The roofline
+ * fraction of bench.py is this over the measured time.  No counterpart in the reference. */
+double trace_profile_pipe_seconds(void);
 
 /* Kernel choice for the full-chip multi-tap convolutions of the denoiser: 0 = conv_bf3_kernel (two workgroups
  * per CU, the default), 1 = conv_ws_kernel (persistent, wave-specialised: csrc/conv_ws_kernels.h), -1 = leave

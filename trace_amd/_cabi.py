@@ -62,6 +62,7 @@ PROTOTYPES = {
     "trace_unet_backward_input": (_I, [_P, _P, _I, _P, _P, _L, _P]),
     "trace_profile_begin": (_I, [_I]),
     "trace_profile_end": (_I, [C.POINTER(C.c_double), C.POINTER(_L), C.POINTER(C.c_double)]),
+    "trace_profile_pipe_seconds": (C.c_double, []),
     "trace_map_query": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F,
                              C.POINTER(DynParams), _P]),
     "trace_dyn_rollout": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(DynParams), _P]),

@@ -33,7 +33,11 @@ void set_error(const char* fmt, ...);
 // the launch stream around every conv_gemm launch while a profile is open.
 bool prof_active();
 void prof_pre(hipStream_t st);
-void prof_post(hipStream_t st, double flops);
+// `pipe_seconds`: the launch's matrix-pipe time at the chip's dense peak (its MFMA FLOPs -- split terms included --
+// over the peak rate of the MFMA type it uses): what the roofline divides by
+void prof_post(hipStream_t st, double flops, double pipe_seconds);
+constexpr double PEAK_MFMA16_FLOPS = 2500e12;    // dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
+constexpr double PEAK_MFMA32_FLOPS = 157.3e12;   // fp32 MFMA
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to a (kernel, device) pair: `done` is one bit
 // per device ordinal, owned by the launcher of one kernel instantiation.  Returns true when the attribute

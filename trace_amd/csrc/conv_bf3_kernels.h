@@ -547,7 +547,10 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   const bool prof = prof_active();
   if (prof) prof_pre(st);
   hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW>), grid, dim3(G::NTH), lds_bytes, st, a);
-  if (prof) prof_post(st, 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT);
+  if (prof) {
+    const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
+    prof_post(st, fl, fl * (SCH == 1 ? 3.0 : 6.0) / PEAK_MFMA16_FLOPS);
+  }
   return launch_status(SCH == 1 ? "conv_bf3_kernel(fp16x2)" : "conv_bf3_kernel");
 }
 

@@ -1146,7 +1146,10 @@ int launch_conv(const ConvArgs& a_in, hipStream_t st) {
   if (prof) prof_pre(st);
   hipLaunchKernelGGL((conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>), grid, dim3(256),
                      lds_bytes, st, a);
-  if (prof) prof_post(st, 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT);
+  if (prof) {
+    const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
+    prof_post(st, fl, fl / PEAK_MFMA32_FLOPS);
+  }
   return launch_status("conv_gemm_kernel");
 }
 

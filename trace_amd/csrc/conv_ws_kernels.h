@@ -728,7 +728,10 @@ int launch_conv_ws(const ConvArgs& a_in, hipStream_t st) {
     hipLaunchKernelGGL((conv_ws_kernel<L_OUT, UP, TAPS, PADL, TB, true>), dim3(grid), dim3(512), W::LDS_BYTES, st, a, ntv);
   else
     hipLaunchKernelGGL((conv_ws_kernel<L_OUT, UP, TAPS, PADL, TB, false>), dim3(grid), dim3(512), W::LDS_BYTES, st, a, ntv);
-  if (prof) prof_post(st, 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT);
+  if (prof) {
+    const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
+    prof_post(st, fl, fl * 6.0 / PEAK_MFMA16_FLOPS);
+  }
   return launch_status("conv_ws_kernel");
 }
 

@@ -65,6 +65,8 @@ struct Prof {
   int n = 0;
   std::vector<hipEvent_t> ev;   // 2 per launch
   std::vector<double> flops;
+  std::vector<double> pipe_s;
+  double last_pipe_s = 0.0;
 } g_prof;
 }  // namespace
 bool prof_active() { return g_prof.on; }
@@ -72,10 +74,11 @@ void prof_pre(hipStream_t st) {
   if (g_prof.n * 2 + 1 >= (int)g_prof.ev.size()) { g_prof.on = false; return; }
   (void)hipEventRecord(g_prof.ev[2 * g_prof.n], st);
 }
-void prof_post(hipStream_t st, double flops) {
+void prof_post(hipStream_t st, double flops, double pipe_seconds) {
   if (!g_prof.on) return;
   (void)hipEventRecord(g_prof.ev[2 * g_prof.n + 1], st);
   g_prof.flops[g_prof.n] = flops;
+  g_prof.pipe_s[g_prof.n] = pipe_seconds;
   ++g_prof.n;
 }
 
@@ -1351,6 +1354,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred, 
 }
 
 // ---- profiling entry points ---------------------------------------------------------------
+extern "C" double trace_profile_pipe_seconds(void) { return g_prof.last_pipe_s; }
 extern "C" int trace_conv_ws_mode(int mode) { return trace::conv_ws_mode(mode); }
 extern "C" int trace_conv_scheme(int mode) { return trace::conv_scheme(mode); }
 
@@ -1359,6 +1363,7 @@ extern "C" int trace_profile_begin(int max_launches) {
   for (hipEvent_t e : g_prof.ev) (void)hipEventDestroy(e);
   g_prof.ev.assign((size_t)max_launches * 2, nullptr);
   g_prof.flops.assign(max_launches, 0.0);
+  g_prof.pipe_s.assign(max_launches, 0.0);
   for (auto& e : g_prof.ev) TRACE_CHECK_HIP(hipEventCreate(&e));
   g_prof.n = 0;
   g_prof.on = true;
@@ -1369,7 +1374,9 @@ extern "C" int trace_profile_end(double* total_ms, int64_t* launches, double* to
   TRACE_REQUIRE(total_ms && launches && total_flops, "trace_profile_end: null argument");
   g_prof.on = false;
   double ms = 0.0, fl = 0.0;
+  g_prof.last_pipe_s = 0.0;
   for (int i = 0; i < g_prof.n; ++i) {
+    g_prof.last_pipe_s += g_prof.pipe_s[i];
     TRACE_CHECK_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
     float t = 0.f;
     TRACE_CHECK_HIP(hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
