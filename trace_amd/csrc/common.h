@@ -90,8 +90,8 @@ __device__ __forceinline__ float mish_fast_f(float x) {
   float w = n + 2.f;
   float r = __builtin_amdgcn_rcpf(w);
   r = __builtin_fmaf(__builtin_fmaf(-w, r, 1.f), r, r);          // one Newton step: <= 0.5 ulp
-  float m = x * (n * r);
-  return x > 20.f ? x : m;
+  // x > 20: the clamped exponent gives n r = 1 to within an ulp, i.e. x itself -- no select needed
+  return x * (n * r);
 }
 
 // d/dx mish(x) = tanh(sp) + x * sigmoid(x) * (1 - tanh(sp)^2),  1 - tanh^2 = 4(n+1)/(n+2)^2
@@ -124,8 +124,8 @@ __device__ __forceinline__ float mish_grad_fast_f(float x) {
   q = __builtin_fmaf(__builtin_fmaf(-e1, q, 1.f), q, q);
   float tsp = n * r;
   float sig = e * q;
-  float g = tsp + x * sig * (4.f * (n + 1.f) * (r * r));
-  return x > 20.f ? 1.f : g;
+  // x > 20: with the clamped exponent the second term is below 2^-24 and tsp is 1 to within an ulp
+  return tsp + x * sig * (4.f * (n + 1.f) * (r * r));
 }
 
 }  // namespace trace

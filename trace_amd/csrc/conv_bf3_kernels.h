@@ -211,8 +211,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   }
   float stg[NUTR][8];
   // the 8 channel loads of unit j of chunk ch (cbase / descriptor choice are wave-uniform)
+  // ch < 0 (no next chunk): the loads are still issued, at an offset outside the descriptor's range (zeros, no
+  // memory access) -- a conditional load would make the compiler copy all staging registers at every chunk
   auto stage_load_unit = [&](int ch, int j) {
     if constexpr (!PLN) {
+      const bool none = ch < 0;
       const bool second = ch >= nch1;
       const int tstride = second ? a.in2_tstride : a.in_tstride;
       const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
@@ -220,7 +223,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
       // units past NU (last pass) read a valid address and are never written to LDS; trajectories
       // past `rows` fall outside the descriptor's range and read as zeros
       const bool live = (NU % NTH == 0) || (tid + NTH * j < NU);
-      const unsigned off = live ? ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u : 0u;
+      const unsigned off = none ? 0xffffe000u
+                                : (live ? ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u : 0u);
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
         stg[j][jj] = second ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, jj * L_IN * 4, 0))
@@ -355,7 +359,11 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 #endif
         }
       }
+#ifdef TRACE_EXP_NOLDSREAD         // timing-only build: the A fragments of the first tiles are reused
+      if (n + DIST < NT && n + DIST < NST) load_a(n + DIST, (n + DIST) % NST);
+#else
       if (n + DIST < NT) load_a(n + DIST, (n + DIST) % NST);
+#endif
 #ifndef TRACE_BF3_PIN
 #define TRACE_BF3_PIN 1           // pin the LDS reads of tile n + DIST ahead of tile n's MFMAs (the scheduler sinks them otherwise)
 #endif
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 #define TRACE_BF3_LOAD_SPREAD 0   // row tiles between the global loads of two staging units of the next chunk (0: all at once)
 #endif
       if constexpr (TRACE_BF3_LOAD_SPREAD == 0) {
-        if (!PLN && n == 1 && (SPLITK || next >= 0)) {
+        if (!PLN && n == 1) {
 #pragma unroll
           for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
         }
@@ -417,6 +425,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   TRACE_STAMP(14);
   for (int ch = 0; ch < nch; ++ch) {
     __syncthreads();            // previous chunk fully consumed (and zero fill done)
+#ifdef TRACE_STAMP_SWITCH       // diagnostic: stamps 4 / 5 = chunk 1's switch (all waves arrived / new image ready)
+    if (ch == 1) TRACE_STAMP(4);
+#endif
     if constexpr (PLN) {
       stage_dma(ch);            // the barrier below waits for it (vmcnt(0) ahead of the s_barrier)
     } else {
@@ -434,6 +445,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     if (ch == 0) TRACE_STAMP(15);
     __syncthreads();
     if (ch == 0) TRACE_STAMP(1);
+#ifdef TRACE_STAMP_SWITCH
+    if (ch == 1) TRACE_STAMP(5);
+#endif
     // with the in-K split the body is branch-free: the last chunk re-stages itself (never written)
 #ifdef TRACE_EXP_NOSTAGE
     const int next = -1;
@@ -457,20 +471,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     }
     // stamps 2, 3: first two chunks; 4, 5: last two (scripts/stamps.py takes the last as the K end)
     if (ch < 2) TRACE_STAMP(2 + ch);
+#ifndef TRACE_STAMP_SWITCH
     else if (ch == nch - 2) TRACE_STAMP(4);
     else if (ch == nch - 1) TRACE_STAMP(5);
+#endif
   }
 
   if constexpr (TRACE_BF3_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-  if constexpr (SCH == 1) {
-#pragma unroll
-    for (int i = 0; i < NACC; ++i) acc[i] *= oscale;
-  }
 #ifndef TRACE_BF3_EPI_REGS
 #define TRACE_BF3_EPI_REGS 0      // forward GroupNorm / Mish on the accumulators (conv_epilogue_fwd_rows)
 #endif
   if constexpr (TRACE_BF3_EPI_REGS && NW == 4) {
-    if (!a.gnb) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0); return; }
+    if (!a.gnb) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0, oscale); return; }
   }
 #ifdef TRACE_EXP_NOEPI
   if (a.rows >= 0) {        // timing-only build: the accumulators stay live, the epilogue never runs
@@ -483,7 +495,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     return;
   }
 #endif
-  conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw);
+  conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw, oscale);
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH = 0, int NW = TRACE_BF3_NW,

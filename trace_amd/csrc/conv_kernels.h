@@ -162,10 +162,16 @@ __device__ __forceinline__ float sub_f16_hi(float a, unsigned h) {
 __device__ __forceinline__ void split8_f16(const float (&v)[8], const float s, u32x4v& h, u32x4v& l) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const float a0 = v[2 * i] * s, a1 = v[2 * i + 1] * s;
-    const unsigned ph = cvt_pk_f16(a0, a1);
+    // h = fp16(v s) in one rounding (mixed-precision FMA writing one half of the register each), l = v s - h
+    // exactly (FMA), then rounded to fp16: five instructions per pair
+    unsigned ph;
+    float l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(ph) : "v"(v[2 * i]), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(ph) : "v"(v[2 * i + 1]), "s"(s));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v[2 * i]), "s"(s), "v"(ph));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v[2 * i + 1]), "s"(s), "v"(ph));
     h[i] = ph;
-    l[i] = cvt_pk_f16(sub_f16_lo(a0, ph), sub_f16_hi(a1, ph));
+    l[i] = cvt_pk_f16(l0, l1);
   }
 }
 
@@ -314,7 +320,7 @@ __device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
 template <int L_OUT, int TB, int ROWMAP = 0, int NW = 4, int NACC = TB * L_OUT / 16>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NACC], float* lds,
                                               const int traj0, const int co0, const int rt0 = 0,
-                                              const int nrtw = NACC) {
+                                              const int nrtw = NACC, const float oscale = 1.f) {
   constexpr int R = TB * L_OUT, NRT = R / 16;
   constexpr int TILE = 64 * L_OUT;
   constexpr int NTH = NW * 64;                       // threads of the workgroup
@@ -382,8 +388,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
         constexpr int PPT = L_OUT / NRT;
         static_assert(PPT * NRT == L_OUT && PPT * TB == 16 && (PPT == 1 || PPT == 2 || PPT == 4),
                       "trajectory-major tiles need L_OUT = 13 PPT and TB = 16 / PPT");
-        f32x4 v = acc[ri];
-        v[0] += bv; v[1] += bv; v[2] += bv; v[3] += bv;
+        f32x4 v = acc[ri];                      // oscale: the fp16 scheme's power of two (1 otherwise: exact)
+        v[0] = fmaf(v[0], oscale, bv); v[1] = fmaf(v[1], oscale, bv);
+        v[2] = fmaf(v[2], oscale, bv); v[3] = fmaf(v[3], oscale, bv);
         if constexpr (PPT == 4) {               // lane group q = trajectory, registers = 4 positions
           *reinterpret_cast<f32x4*>(tcol + q * TILE + 4 * rt) = v;
         } else if constexpr (PPT == 2) {        // registers 0,1 / 2,3 = two positions of trajectories 2q / 2q+1
@@ -431,7 +438,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
         int rem;
         const unsigned oo = flat_off(k, a.raw_tstride, a.raw_coff, rem);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rw, oo, 0, 0);
-        if (oo != 0xffffffffu) mraw = amax4(mraw, y);
+        mraw = amax4(mraw, y);       // cells past the tile repeat cell 0, rows past `rows` hold the conv of zeros
       }
       if (flat_live(k)) *reinterpret_cast<f32x4*>(cell) = y;
     }
@@ -535,7 +542,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
       int rem;
       const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
-      if (oo != 0xffffffffu) mout = amax4(mout, y);
+      mout = amax4(mout, y);
     }
     if (a.out_amax) record_amax(a.out_amax, traj0, mout);
     if (a.outp)                                // the tile still holds d/dy
@@ -689,7 +696,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
     y += rv[k];
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
-    if (oo != 0xffffffffu) mout = amax4(mout, y);
+    mout = amax4(mout, y);
     if (a.outp && flat_live(k)) *reinterpret_cast<f32x4*>(lds_cell(k)) = y;      // the finished value, for the planes
   }
   if (a.out_amax) record_amax(a.out_amax, traj0, mout);
@@ -711,7 +718,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
 // partial sums through 512 B of LDS behind the tile.
 template <int L_OUT, int TB>
 __device__ __forceinline__ void conv_epilogue_fwd_rows(const ConvArgs& a, f32x4 (&acc)[TB * L_OUT / 16],
-                                                       float* lds, const int traj0, const int co0) {
+                                                       float* lds, const int traj0, const int co0,
+                                                       const float oscale = 1.f) {
   constexpr int R = TB * L_OUT, NRT = R / 16, PPT = L_OUT / NRT, NPR = 4 / PPT;
   constexpr int TILE = 64 * L_OUT;
   constexpr int NQ = R * 64 / 4 / 256;
@@ -755,7 +763,10 @@ __device__ __forceinline__ void conv_epilogue_fwd_rows(const ConvArgs& a, f32x4 
   {  // conv bias
     const float bv = a.bias ? a.bias[co] : 0.f;
 #pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) { acc[rt][0] += bv; acc[rt][1] += bv; acc[rt][2] += bv; acc[rt][3] += bv; }
+    for (int rt = 0; rt < NRT; ++rt) {
+      acc[rt][0] = fmaf(acc[rt][0], oscale, bv); acc[rt][1] = fmaf(acc[rt][1], oscale, bv);
+      acc[rt][2] = fmaf(acc[rt][2], oscale, bv); acc[rt][3] = fmaf(acc[rt][3], oscale, bv);
+    }
   }
   // accumulators -> tile laid out like the global tensor ([trajectory][channel][position])
   auto write_tile = [&]() {
@@ -882,12 +893,15 @@ __device__ __forceinline__ void conv_epilogue_fwd_rows(const ConvArgs& a, f32x4 
   TRACE_STAMP(9);
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
       a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
+  float mout = 0.f;
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     f32x4 y = *reinterpret_cast<const f32x4*>(lds + (tid + 256 * k) * 4);
     y += rv[k];
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, flat_off(k, a.out_tstride, a.out_coff), 0, 0);
+    mout = amax4(mout, y);
   }
+  if (a.out_amax) record_amax(a.out_amax, traj0, mout);
   TRACE_STAMP(11);
 }
 
