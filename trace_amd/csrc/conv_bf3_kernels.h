@@ -37,14 +37,17 @@ namespace trace {
 #ifndef TRACE_BF3_NW
 #define TRACE_BF3_NW 4            // waves per workgroup of the full-chip launches (small launches: launch_conv_bf3)
 #endif
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW>
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW, int CHN = 32>
 struct Bf3Geom {
   static constexpr int NTH = NW * 64;                      // threads per workgroup
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
   // wave w owns column tile w & 3 and part w >> 2 of the row tiles: the NRT tiles are dealt to NW / 4 parts,
   // the first NRT % NPART parts take one more
   static constexpr int NPART = NW / 4;
-  static constexpr int CH = 32;                            // channels per chunk = one MFMA k-slice per tap
+  static_assert(CHN == 32 || CHN == 64, "chunks of 32 or 64 channels");
+  static constexpr int CH = CHN;                           // channels per chunk = CH / 32 MFMA k-slices per tap
+  static constexpr int NOCT = CH / 8;                      // channel octets = (plane, octet) arrays per plane
+  static constexpr int NPLMAX = CHN == 32 ? 3 : 2;         // 64-channel chunks exist for the two-plane scheme only
   static constexpr int R = TB * L_OUT;
   static constexpr int NRT = R / 16;
   static constexpr int PPT = L_OUT / NRT;                  // positions per row tile (4, 2, 1)
@@ -60,7 +63,7 @@ struct Bf3Geom {
   static constexpr int S = TB * LP;
   static constexpr int L_IN = L_OUT / UP;
   static constexpr int SUB = (S * 16 + 255) / 256 * 256;   // bytes of one (plane, channel octet) array
-  static constexpr int PLANE = 4 * SUB;                    // bytes per plane
+  static constexpr int PLANE = NOCT * SUB;                 // bytes per plane
   static constexpr int NPOS = TB * L_IN;                   // data positions per chunk
   static constexpr int NU = NPOS * (CH / 8);               // staging units (position, channel octet)
   static constexpr int NUT = (NU + NTH - 1) / NTH;
@@ -68,9 +71,9 @@ struct Bf3Geom {
   static constexpr int NREM = NRT % NPART;                     // parts that have NACC tiles (0: all of them)
   // the output tile (conv_epilogue) + the 32-channel-group exchange area of conv_epilogue_fwd_rows
   static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float) + 2 * 4 * TB * sizeof(float);
-  static constexpr size_t LDS_BYTES = (size_t)3 * PLANE > EPI_BYTES ? (size_t)3 * PLANE : EPI_BYTES;
+  static constexpr size_t LDS_BYTES = (size_t)NPLMAX * PLANE > EPI_BYTES ? (size_t)NPLMAX * PLANE : EPI_BYTES;
   static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0 && PPT * NRT == L_OUT && PPT * TB == 16, "bad tile");
-  static_assert(3 * PLANE < 65536, "LDS immediates must fit 16 bits");
+  static_assert(PLANE + NOCT * SUB < 131072, "plane offsets stay small");
 };
 
 #ifndef TRACE_BF3_WGS
@@ -89,11 +92,15 @@ struct Bf3Geom {
 //          product; MFMA honours fp16 subnormal inputs, so small low terms degrade gracefully).  Measured against
 //          an fp64 sum at K = 1280 (scripts/probe/f16x2.hip): rms relative error 3.6e-7 (bf16 x 3: 5.3e-7, the fp32
 //          MFMA 5.8e-7 -- half the fp32 accumulations), at twice the rate.  Same LDS image, tile and epilogue.
+// CHN = channels per chunk (LDS image / barrier pair): 32, or 64 for the fp16 scheme (half the chunk switches; the
+//       two k-slices of a tap are multiplied one after the other, the next chunk's loads issued half in each).
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32>
 __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW>;
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN>;
   static_assert(SCH == 0 || (SCH == 1 && !PLN), "two schemes; the plane tensors are bf16 x 3 only");
+  static_assert(CHN == 32 || SCH == 1, "64-channel chunks: fp16 scheme only");
+  constexpr int NH = CHN / 32;                   // k-slices per tap and chunk
   constexpr int NPL = SCH == 1 ? 2 : 3;
   constexpr int LP = G::LP, L_IN = G::L_IN, SUB = G::SUB, PLANE = G::PLANE;
   constexpr int NUT = G::NUT, NU = G::NU, NPOS = G::NPOS, CH = G::CH, NTH = G::NTH, NACC = G::NACC;
@@ -236,25 +243,32 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 #define TRACE_BF3_SPLIT_IN_K 0    // split the next chunk into bf16 planes between the MFMAs of the current one
 #endif
   constexpr bool SPLITK = TRACE_BF3_SPLIT_IN_K && TAPS > 1 && !PLN;     // the 1x1 kernels have no MFMA shadow to hide it in
-  u32x4v sph[NUTR], spm[SCH == 1 ? 1 : NUTR], spl[NUTR];
+  constexpr int NUTS = SCH == 1 ? 1 : NUTR;      // the fp16 scheme splits inside stage_write
+  u32x4v sph[NUTS], spm[NUTS], spl[NUTS];
   auto split_unit = [&](int j) {
-    if constexpr (SCH == 1) split8_f16(stg[j], ascale, sph[j], spl[j]);
-    else if constexpr (!PLN) split8_bf16(stg[j], sph[j], spm[j], spl[j]);
+    if constexpr (SCH == 0 && !PLN) split8_bf16(stg[j], sph[j], spm[j], spl[j]);
   };
   // the bf16 planes of the staged chunk go to LDS from sph / spm / spl
   auto stage_write = [&]() {
-    if constexpr (!PLN) {
+    if constexpr (SCH == 1) {                    // split and write unit by unit: no second register set
+#pragma unroll
+      for (int j = 0; j < NUT; ++j) {
+        u32x4v h, l;
+        split8_f16(stg[j], ascale, h, l);
+        if ((NU % NTH == 0) || (tid + NTH * j < NU)) {
+          char* p = ldsb + wofs[j];
+          *reinterpret_cast<u32x4v*>(p) = h;
+          *reinterpret_cast<u32x4v*>(p + PLANE) = l;
+        }
+      }
+    } else if constexpr (!PLN) {
 #pragma unroll
       for (int j = 0; j < NUT; ++j) {
         if ((NU % NTH == 0) || (tid + NTH * j < NU)) {
           char* p = ldsb + wofs[j];
           *reinterpret_cast<u32x4v*>(p) = sph[j];
-          if constexpr (SCH == 1) {
-            *reinterpret_cast<u32x4v*>(p + PLANE) = spl[j];
-          } else {
-            *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
-            *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = spl[j];
-          }
+          *reinterpret_cast<u32x4v*>(p + PLANE) = spm[j];
+          *reinterpret_cast<u32x4v*>(p + 2 * PLANE) = spl[j];
         }
       }
     }
@@ -267,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     if constexpr (UP == 1 && TAPS == 1) {
     } else if constexpr (UP == 1) {
       constexpr int HALO = LP - L_IN;                      // PADL cells in front of the data, the rest behind
-      for (int i = tid; i < 4 * NPL * TB * HALO; i += NTH) {    // (plane, octet) arrays x trajectories x halo cells
+      for (int i = tid; i < G::NOCT * NPL * TB * HALO; i += NTH) {    // (plane, octet) arrays x trajectories x halo cells
         const int arr = i / (TB * HALO);
         const int r0 = i - arr * (TB * HALO);
         const int tr = r0 / HALO;
@@ -320,14 +334,16 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   // one chunk's MFMAs over taps [T0, T1); the next chunk's activations (chunk `next`, -1 = none) are
   // requested one staging unit at a time between row tiles, after the slice's weight loads, so that
   // neither the issue of 32 loads in a row nor a vmcnt wait for weights stalls on them
-  auto chunk_mma = [&](auto t0c, auto t1c, auto nrc, const int next) {
+  auto chunk_mma = [&](auto t0c, auto t1c, auto nrc, const int next, auto halfc) {
     constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NR = decltype(nrc)::value;
+    constexpr int HALF = decltype(halfc)::value;                               // k-slice of the chunk: octets 4 HALF ..
+    constexpr int J0 = (HALF * NUT) / NH, J1 = ((HALF + 1) * NUT) / NH;        // staging units loaded beside it
     constexpr int NT = (T1 - T0) * NR;
     constexpr int NST = TAPS == 1 ? (TRACE_BF3_NST < 3 ? TRACE_BF3_NST : 3) : TRACE_BF3_NST, DIST = NST - 1;   // A register stages / prefetch distance in tiles
     bf16x8 av[NST][NPL];
     auto load_a = [&](int n, int stage) {
       const int tap = T0 + n / NR, rt = n % NR;
-      const char* p = ldsb + tapoff[tap] + rt * PPT * 16;
+      const char* p = ldsb + tapoff[tap] + rt * PPT * 16 + HALF * 4 * SUB;
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) av[stage][pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
     };
@@ -374,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
       if constexpr (TRACE_BF3_LOAD_SPREAD == 0) {
         if (!PLN && n == 1) {
 #pragma unroll
-          for (int j = 0; j < NUT; ++j) stage_load_unit(next, j);
+          for (int j = J0; j < J1; ++j) stage_load_unit(next, j);
         }
       } else {
         constexpr int SP = (NT - 2) / NUT < TRACE_BF3_LOAD_SPREAD ? ((NT - 2) / NUT > 0 ? (NT - 2) / NUT : 1) : TRACE_BF3_LOAD_SPREAD;
@@ -461,12 +477,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     {
       using NRC = std::integral_constant<int, NACC>;
       using NRC2 = std::integral_constant<int, NREM != 0 ? NACC - 1 : NACC>;
+      using IC1 = std::integral_constant<int, 1>;
       if (NREM == 0 || rpart < NREM) {                     // wave-uniform
-        if (ch < nch1) chunk_mma(IC0{}, ICT{}, NRC{}, next);
-        else chunk_mma(ICP{}, ICP1{}, NRC{}, next);
+        if (ch < nch1) {
+          chunk_mma(IC0{}, ICT{}, NRC{}, next, IC0{});
+          if constexpr (NH == 2) chunk_mma(IC0{}, ICT{}, NRC{}, next, IC1{});
+        } else {
+          chunk_mma(ICP{}, ICP1{}, NRC{}, next, IC0{});
+          if constexpr (NH == 2) chunk_mma(ICP{}, ICP1{}, NRC{}, next, IC1{});
+        }
       } else if constexpr (NREM != 0) {
-        if (ch < nch1) chunk_mma(IC0{}, ICT{}, NRC2{}, next);
-        else chunk_mma(ICP{}, ICP1{}, NRC2{}, next);
+        if (ch < nch1) chunk_mma(IC0{}, ICT{}, NRC2{}, next, IC0{});
+        else chunk_mma(ICP{}, ICP1{}, NRC2{}, next, IC0{});
       }
     }
     // stamps 2, 3: first two chunks; 4, 5: last two (scripts/stamps.py takes the last as the K end)
@@ -499,9 +521,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH = 0, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32>
 int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW>;
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN>;
+  static_assert(CHN == 32 || NW == 4, "64-channel chunks: 4-wave workgroups");
   ConvArgs a = a_in;
   if (a.rows <= 0) return TRACE_OK;
   TRACE_REQUIRE(!PLN || (a.inp && a.zero_cell && a.inp_noct > 0 && (a.cin2 == 0 || (a.in2p && a.in2p_noct > 0)) &&
@@ -512,7 +535,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
                 "conv(bf16x3): bad output plane tensor");
   TRACE_REQUIRE(SCH == 0 || (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax) && a.wexp >= -10 && a.wexp <= 40),
                 "conv(fp16x2): weight stream, weight exponent or input amax missing");
-  TRACE_REQUIRE((SCH == 1 || a.wb) && a.cout % 64 == 0 && a.cin % 32 == 0 && a.cin2 % 32 == 0 &&
+  TRACE_REQUIRE((SCH == 1 || a.wb) && a.cout % 64 == 0 && a.cin % CHN == 0 && a.cin2 % CHN == 0 &&
                     a.nsl == TAPS * a.cin / 32 + a.cin2 / 32,
                 "conv(bf16x3): bad channel geometry cin=%d cin2=%d cout=%d nsl=%d", a.cin, a.cin2, a.cout,
                 a.nsl);
@@ -548,7 +571,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   static unsigned long long attr_done = 0;      // one bit per device
   if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW>),
+        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   }
   const int nrb = (a.rows + TB - 1) / TB;
@@ -558,7 +581,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
 #endif
   const bool prof = prof_active();
   if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW>), grid, dim3(G::NTH), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN>), grid, dim3(G::NTH), lds_bytes, st, a);
   if (prof) {
     const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
     prof_post(st, fl, fl * (SCH == 1 ? 3.0 : 6.0) / PEAK_MFMA16_FLOPS);
@@ -586,9 +609,19 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
   if (a.inp && (a.cin2 == 0 || a.in2p)) return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, true, 0>(a, st);
   const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
   if (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax)) {          // every operand has its scale: the fp16 pipe
-    static const int small_max16 = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
+    // small launches: measured on cfg1 (320 trajectories, 80 workgroups) the 4-wave kernel is the fastest form of
+    // the fp16 scheme (90.6 ms per call; 8 waves 96.4, 16 waves 107.3 -- those instantiations spill), so the
+    // many-wave form is opt-in here (TRACE_F16_SMALL_MAX = largest launch, in workgroups, that takes it)
+    static const int small_max16 = getenv("TRACE_F16_SMALL_MAX") ? atoi(getenv("TRACE_F16_SMALL_MAX")) : 0;
     if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max16)
       return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
+#ifndef TRACE_F16_CH
+#define TRACE_F16_CH 64           // channels per chunk of the full-chip fp16 launches with more than one tap (32 / 64)
+#endif
+    if constexpr (TRACE_F16_CH == 64 && TAPS > 1) {
+      if (a.cin % 64 == 0 && a.cin2 % 64 == 0)
+        return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_NW, TRACE_BF3_WGS * TRACE_BF3_NW / 4, 64>(a, st);
+    }
     return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1>(a, st);
   }
   static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
