@@ -37,8 +37,10 @@ namespace trace {
 #ifndef TRACE_BF3_NW
 #define TRACE_BF3_NW 4            // waves per workgroup of the full-chip launches (small launches: launch_conv_bf3)
 #endif
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW, int CHN = 32>
+// IS = input stride (2: the down-sampling convs and the transposed convs' dgrad), UP = zero-stuffing factor
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW, int CHN = 32, int IS = 1>
 struct Bf3Geom {
+  static_assert(IS == 1 || (IS == 2 && UP == 1), "stride 2 without zero-stuffing");
   static constexpr int NTH = NW * 64;                      // threads per workgroup
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
   // wave w owns column tile w & 3 and part w >> 2 of the row tiles: the NRT tiles are dealt to NW / 4 parts,
@@ -59,9 +61,9 @@ struct Bf3Geom {
     while (!(TB == 4 ? (lp % 16 == 4 || lp % 16 == 12) : TB == 8 ? (lp % 2 == 0 && (lp / 2) % 2 == 1) : lp % 2 == 1)) ++lp;
     return lp;
   }
-  static constexpr int LP = lp_pad((L_OUT - 1) + TAPS);
+  static constexpr int LP = lp_pad((L_OUT - 1) * IS + TAPS);
   static constexpr int S = TB * LP;
-  static constexpr int L_IN = L_OUT / UP;
+  static constexpr int L_IN = L_OUT * IS / UP;
   static constexpr int SUB = (S * 16 + 255) / 256 * 256;   // bytes of one (plane, channel octet) array
   static constexpr int PLANE = NOCT * SUB;                 // bytes per plane
   static constexpr int NPOS = TB * L_IN;                   // data positions per chunk
@@ -95,9 +97,10 @@ struct Bf3Geom {
 // CHN = channels per chunk (LDS image / barrier pair): 32, or 64 for the fp16 scheme (half the chunk switches; the
 //       two k-slices of a tap are multiplied one after the other, the next chunk's loads issued half in each).
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1>
 __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN>;
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS>;
+  static_assert(IS == 1 || !PLN, "stride 2: register staging only");
   static_assert(SCH == 0 || (SCH == 1 && !PLN), "two schemes; the plane tensors are bf16 x 3 only");
   static_assert(CHN == 32 || SCH == 1, "64-channel chunks: fp16 scheme only");
   constexpr int NH = CHN / 32;                   // k-slices per tap and chunk
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NUT; ++j) stage_load_unit(0, j);
     // halo / zero-stuffing positions are written once; data positions are rewritten by every chunk
-    if constexpr (UP == 1 && TAPS == 1) {
+    if constexpr (UP == 1 && TAPS == 1 && IS == 1) {
     } else if constexpr (UP == 1) {
       constexpr int HALO = LP - L_IN;                      // PADL cells in front of the data, the rest behind
       for (int i = tid; i < G::NOCT * NPL * TB * HALO; i += NTH) {    // (plane, octet) arrays x trajectories x halo cells
@@ -300,13 +303,13 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   // its output row (trajectory i / PPT, position PPT rt + i % PPT): one ds_read_b128 per plane, and
   // the row tiles differ by a constant (PPT cells)
   constexpr int PPT = G::PPT;
-  const int rowoff0 = (((lane & 15) / PPT) * LP + (lane & 15) % PPT) * 16 + (lane >> 4) * SUB;
+  const int rowoff0 = (((lane & 15) / PPT) * LP + ((lane & 15) % PPT) * IS) * 16 + (lane >> 4) * SUB;
   // one base per tap, made opaque: tile rt at tap t and tile rt - 1 at tap t + PPT read the same cell,
   // and if the compiler can see that it merges the reads and keeps the fragments live (spills)
   int tapoff[TAPS];
 #pragma unroll
   for (int t = 0; t < TAPS; ++t) {
-    tapoff[t] = rowoff0 + t * 16 + rt0 * PPT * 16;
+    tapoff[t] = rowoff0 + t * 16 + rt0 * PPT * IS * 16;
     asm volatile("" : "+v"(tapoff[t]));
   }
   f32x4 acc[NACC];
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
     bf16x8 av[NST][NPL];
     auto load_a = [&](int n, int stage) {
       const int tap = T0 + n / NR, rt = n % NR;
-      const char* p = ldsb + tapoff[tap] + rt * PPT * 16 + HALF * 4 * SUB;
+      const char* p = ldsb + tapoff[tap] + rt * PPT * IS * 16 + HALF * 4 * SUB;
 #pragma unroll
       for (int pl = 0; pl < NPL; ++pl) av[stage][pl] = *reinterpret_cast<const bf16x8*>(p + pl * PLANE);
     };
@@ -521,9 +524,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH = 0, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1>
 int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN>;
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS>;
   static_assert(CHN == 32 || NW == 4, "64-channel chunks: 4-wave workgroups");
   ConvArgs a = a_in;
   if (a.rows <= 0) return TRACE_OK;
@@ -539,7 +542,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
                     a.nsl == TAPS * a.cin / 32 + a.cin2 / 32,
                 "conv(bf16x3): bad channel geometry cin=%d cin2=%d cout=%d nsl=%d", a.cin, a.cin2, a.cout,
                 a.nsl);
-  TRACE_REQUIRE(a.cin2 == 0 || (a.in2 && UP == 1 && a.in2_tstride % 4 == 0 &&
+  TRACE_REQUIRE(a.cin2 == 0 || (a.in2 && UP == 1 && IS == 1 && a.in2_tstride % 4 == 0 &&
                                 (size_t)(a.rows + TB) * a.in2_tstride * sizeof(float) < 0xffffffffull),
                 "conv(bf16x3): second K source needs a stride-1 conv and a tensor below 4 GiB");
   TRACE_REQUIRE(!a.gnb || (!a.gn && !a.pc && !a.ysave && a.gb_y && a.gb_stats && a.gb_gamma && a.gb_beta &&
@@ -564,14 +567,17 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
                 "conv(bf16x3): output / residual tensors must be 16-byte aligned per trajectory tile and "
                 "below 4 GiB (%d rows)", a.rows);
   TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
-  static_assert(G::LDS_BYTES <= 80 * 1024, "conv(bf16x3): LDS per workgroup too large for two per CU");
+  constexpr size_t LDS_NEED = (size_t)(SCH == 1 ? 2 : 3) * G::PLANE > G::EPI_BYTES ? (size_t)(SCH == 1 ? 2 : 3) * G::PLANE
+                                                                                   : G::EPI_BYTES;
+  // two workgroups per CU (the stride-2 bf16-triple fallback, 83 KB, runs one per CU)
+  static_assert(LDS_NEED <= (IS == 2 && SCH == 0 ? 100 : 80) * 1024, "conv(bf16x3): LDS per workgroup too large");
   // TRACE_EXP_ONE_WG=1 (experiment): pad the LDS request so that only ONE workgroup fits a CU
   static const bool one_wg = getenv("TRACE_EXP_ONE_WG") && atoi(getenv("TRACE_EXP_ONE_WG")) != 0;
-  const size_t lds_bytes = one_wg ? (size_t)100 * 1024 : G::LDS_BYTES;
+  const size_t lds_bytes = one_wg ? (size_t)100 * 1024 : LDS_NEED;
   static unsigned long long attr_done = 0;      // one bit per device
   if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN>),
+        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   }
   const int nrb = (a.rows + TB - 1) / TB;
@@ -581,7 +587,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
 #endif
   const bool prof = prof_active();
   if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN>), grid, dim3(G::NTH), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS>), grid, dim3(G::NTH), lds_bytes, st, a);
   if (prof) {
     const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
     prof_post(st, fl, fl * (SCH == 1 ? 3.0 : 6.0) / PEAK_MFMA16_FLOPS);
@@ -603,6 +609,15 @@ template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_ws(const ConvArgs& a_in, hipStream_t st);      // conv_ws_kernels.h
 int conv_ws_mode(int mode);                                    // unet.hip (trace_conv_ws_mode)
 int conv_scheme(int mode);                                     // unet.hip (trace_conv_scheme): 0 bf16 x 3, 1 fp16 x 2 where possible
+
+// stride-2 convs (4-wave workgroups, 32-channel chunks: a chunk already stages 2 L_OUT positions per trajectory)
+template <int L_OUT, int TAPS, int PADL, int TB>
+int launch_conv_bf3_s2(const ConvArgs& a, hipStream_t st) {
+  constexpr int MW = TRACE_BF3_WGS * TRACE_BF3_NW / 4;
+  if (a.wh && a.in_amax)
+    return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, false, 1, TRACE_BF3_NW, MW, 32, 2>(a, st);
+  return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, false, 0, TRACE_BF3_NW, MW, 32, 2>(a, st);
+}
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {

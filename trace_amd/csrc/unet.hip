@@ -917,8 +917,18 @@ int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
         if (L_out == 52) return launch_conv_bf3<52, 2, 3, 1, 4>(a, st);
         if (L_out == 26) return launch_conv_bf3<26, 2, 3, 1, 8>(a, st);
         break;
+      case K_DOWN_F:      // Conv1d k3 s2 p1
+        if (getenv("TRACE_S2_FP32")) break;
+        if (L_out == 26) return launch_conv_bf3_s2<26, 3, 1, 8>(a, st);
+        if (L_out == 13) return launch_conv_bf3_s2<13, 3, 1, 16>(a, st);
+        break;
+      case K_UP_B:        // dgrad of ConvTranspose1d k4 s2 p1
+        if (getenv("TRACE_S2_FP32")) break;
+        if (L_out == 26) return launch_conv_bf3_s2<26, 4, 1, 8>(a, st);
+        if (L_out == 13) return launch_conv_bf3_s2<13, 4, 1, 16>(a, st);
+        break;
       default:
-        break;          // stride-2 convs: fp32 kernel below
+        break;
     }
   }
   switch (kind) {
