@@ -628,7 +628,7 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
     // the fp16 scheme (90.6 ms per call; 8 waves 96.4, 16 waves 107.3 -- those instantiations spill), so the
     // many-wave form is opt-in here (TRACE_F16_SMALL_MAX = largest launch, in workgroups, that takes it)
     static const int small_max16 = getenv("TRACE_F16_SMALL_MAX") ? atoi(getenv("TRACE_F16_SMALL_MAX")) : 0;
-    if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max16)
+    if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max16 && (L_OUT < 52 || getenv("TRACE_F16_SMALL_L52")))
       return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
 #ifndef TRACE_F16_CH
 #define TRACE_F16_CH 64           // channels per chunk of the full-chip fp16 launches with more than one tap (32 / 64)
