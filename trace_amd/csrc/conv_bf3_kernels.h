@@ -98,7 +98,7 @@ struct Bf3Geom {
 //       two k-slices of a tap are multiplied one after the other, the next chunk's loads issued half in each).
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
           int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1>
-__global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, const int ct) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS>;
   static_assert(IS == 1 || !PLN, "stride 2: register staging only");
   static_assert(SCH == 0 || (SCH == 1 && !PLN), "two schemes; the plane tensors are bf16 x 3 only");
@@ -120,11 +120,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   constexpr int NREM = G::NREM;
   const int nrtw = (NREM == 0 || rpart < NREM) ? NACC : NACC - 1;
   const int rt0 = NREM == 0 ? rpart * NACC : (rpart < NREM ? rpart * NACC : NREM * NACC + (rpart - NREM) * (NACC - 1));
-  // workgroup id -> (row block, column tile): see conv_gemm_kernel
-  const int ncol = a.cout >> 6;
-  const int bid = blockIdx.x;
-  const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
-  const int ct = (bid >> 3) % ncol;
   if (rb * TB >= a.rows) return;
   const int traj0 = rb * TB;
   const int co0 = ct * 64;
@@ -521,6 +516,74 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   }
 #endif
   conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw, oscale);
+}
+
+// workgroup id -> (row block, column tile): the ncol column tiles of one row block get ids of the same residue
+// mod 8, 8 apart (same XCD, same time: see conv_gemm_kernel)
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1>
+__global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
+  const int ncol = a.cout >> 6;
+  const int bid = blockIdx.x;
+  conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS>(a, (bid / (8 * ncol)) * 8 + (bid & 7),
+                                                                       (bid >> 3) % ncol);
+}
+
+// A residual block's first k5 conv (a) and its 1x1 residual conv (b) read the same input: one launch, the column
+// tiles of b behind those of a in every row block, so the 1x1 workgroups run beside the k5 workgroups of their
+// row block (same XCD: the input comes from L2) and fill matrix-pipe time the memory-bound 1x1 launch left idle.
+template <int L_OUT, int TB, int CHN>
+__global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvArgs a, ConvArgs b) {
+  const int ncol_a = a.cout >> 6;
+  const int ncol = ncol_a + (b.cout >> 6);
+  const int bid = blockIdx.x;
+  const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
+  const int ct = (bid >> 3) % ncol;
+  if (ct < ncol_a) conv_bf3_body<L_OUT, 1, 5, 2, TB, false, 1, 4, 2, CHN, 1>(a, rb, ct);
+  else conv_bf3_body<L_OUT, 1, 1, 0, TB, false, 1, 4, 2, 32, 1>(b, rb, ct - ncol_a);
+}
+
+template <int L_OUT, int TB>
+int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
+  constexpr int CHN = 64;
+  using GA = Bf3Geom<L_OUT, 1, 5, 2, TB, 4, CHN, 1>;
+  using GB = Bf3Geom<L_OUT, 1, 1, 0, TB, 4, 32, 1>;
+  if (a.rows <= 0) return TRACE_OK;
+  TRACE_REQUIRE(a.rows == b.rows && a.in == b.in && a.in_coff == b.in_coff && a.in_tstride == b.in_tstride,
+                "conv pair: the two convs must read the same input");
+  TRACE_REQUIRE(a.wh && b.wh && a.in_amax && b.in_amax && a.cin2 == 0 && b.cin2 == 0 && a.cin % 64 == 0 &&
+                    b.cin % 32 == 0 && a.cout % 64 == 0 && b.cout % 64 == 0 &&
+                    a.nsl == 5 * a.cin / 32 && b.nsl == b.cin / 32 && !a.gnb && !b.gnb && !b.gn && !b.pc,
+                "conv pair: bad geometry cin=%d/%d cout=%d/%d", a.cin, b.cin, a.cout, b.cout);
+  auto ok128 = [&](const ConvArgs& c, const float* p, int tstride, int coff) {
+    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 && (coff * L_OUT) % 4 == 0 &&
+                            (size_t)c.rows * tstride * sizeof(float) < 0xffffffffull);
+  };
+  TRACE_REQUIRE((reinterpret_cast<uintptr_t>(a.in) & 3) == 0 &&
+                    (size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull &&
+                    ok128(a, a.out, a.out_tstride, a.out_coff) && ok128(b, b.out, b.out_tstride, b.out_coff) &&
+                    ok128(a, a.res, a.res_tstride, a.res_coff) && ok128(a, a.ysave, a.cout * L_OUT, 0) && !b.res &&
+                    !b.ysave && !a.res2 && !b.res2 && (!a.pc || a.pt),
+                "conv pair: tensors must be 16-byte aligned per trajectory tile and below 4 GiB");
+  constexpr size_t la = (size_t)2 * GA::PLANE > GA::EPI_BYTES ? (size_t)2 * GA::PLANE : GA::EPI_BYTES;
+  constexpr size_t lb = (size_t)2 * GB::PLANE > GB::EPI_BYTES ? (size_t)2 * GB::PLANE : GB::EPI_BYTES;
+  constexpr size_t lds_bytes = la > lb ? la : lb;
+  static_assert(lds_bytes <= 80 * 1024, "conv pair: LDS per workgroup too large for two per CU");
+  static unsigned long long attr_done = 0;
+  if (first_launch_on_device(&attr_done)) {
+    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<L_OUT, TB, CHN>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+  }
+  const int nrb = (a.rows + TB - 1) / TB;
+  dim3 grid(((nrb + 7) / 8) * 8 * ((a.cout + b.cout) / 64));
+  const bool prof = prof_active();
+  if (prof) prof_pre(st);
+  hipLaunchKernelGGL((conv_pair_kernel<L_OUT, TB, CHN>), grid, dim3(256), lds_bytes, st, a, b);
+  if (prof) {
+    const double fl = 2.0 * (a.alg_macs_per_pos + b.alg_macs_per_pos) * (double)a.rows * L_OUT;
+    prof_post(st, fl, fl * 3.0 / PEAK_MFMA16_FLOPS);
+  }
+  return launch_status("conv_pair_kernel");
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH = 0, int NW = TRACE_BF3_NW,
