@@ -38,14 +38,17 @@ namespace trace {
 #define TRACE_BF3_NW 4            // waves per workgroup of the full-chip launches (small launches: launch_conv_bf3)
 #endif
 // IS = input stride (2: the down-sampling convs and the transposed convs' dgrad), UP = zero-stuffing factor
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW, int CHN = 32, int IS = 1>
+// WIDE: an 8-wave workgroup that owns 128 output channels (wave w = column tile w, all row tiles) instead of 64
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW, int CHN = 32, int IS = 1,
+          bool WIDE = false>
 struct Bf3Geom {
+  static_assert(!WIDE || NW == 8, "wide workgroups have 8 waves");
   static_assert(IS == 1 || (IS == 2 && UP == 1), "stride 2 without zero-stuffing");
   static constexpr int NTH = NW * 64;                      // threads per workgroup
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
   // wave w owns column tile w & 3 and part w >> 2 of the row tiles: the NRT tiles are dealt to NW / 4 parts,
   // the first NRT % NPART parts take one more
-  static constexpr int NPART = NW / 4;
+  static constexpr int NPART = WIDE ? 1 : NW / 4;
   static_assert(CHN == 32 || CHN == 64, "chunks of 32 or 64 channels");
   static constexpr int CH = CHN;                           // channels per chunk = CH / 32 MFMA k-slices per tap
   static constexpr int NOCT = CH / 8;                      // channel octets = (plane, octet) arrays per plane
@@ -97,9 +100,10 @@ struct Bf3Geom {
 // CHN = channels per chunk (LDS image / barrier pair): 32, or 64 for the fp16 scheme (half the chunk switches; the
 //       two k-slices of a tap are multiplied one after the other, the next chunk's loads issued half in each).
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1, bool WIDE = false>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, const int ct) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS>;
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS, WIDE>;
+  static_assert(!WIDE || (SCH == 1 && !PLN), "wide workgroups: fp16 scheme");
   static_assert(IS == 1 || !PLN, "stride 2: register staging only");
   static_assert(SCH == 0 || (SCH == 1 && !PLN), "two schemes; the plane tensors are bf16 x 3 only");
   static_assert(CHN == 32 || SCH == 1, "64-channel chunks: fp16 scheme only");
@@ -115,14 +119,14 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   const int wave = tid >> 6;
   // wave -> (column tile, row tiles).  A workgroup's waves go to the SIMDs cyclically, so the waves of one
   // column tile (w, w + 4, ...) share a SIMD and every SIMD carries the same MFMA load.
-  const int cwave = wave & 3;
-  const int rpart = wave >> 2;
+  const int cwave = WIDE ? wave : (wave & 3);
+  const int rpart = WIDE ? 0 : (wave >> 2);
   constexpr int NREM = G::NREM;
   const int nrtw = (NREM == 0 || rpart < NREM) ? NACC : NACC - 1;
   const int rt0 = NREM == 0 ? rpart * NACC : (rpart < NREM ? rpart * NACC : NREM * NACC + (rpart - NREM) * (NACC - 1));
   if (rb * TB >= a.rows) return;
   const int traj0 = rb * TB;
-  const int co0 = ct * 64;
+  const int co0 = ct * (WIDE ? 128 : 64);
   TRACE_STAMP(0);
 #ifdef TRACE_CONV_STAMPS
   if (a.dbg && threadIdx.x == 0) {
@@ -313,7 +317,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 
   // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
   constexpr int WSL = 64 * NPL;                  // fragments per slice
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(SCH == 1 ? a.wh : a.wb) + ((size_t)(ct * 4 + cwave) * a.nsl) * WSL + lane;
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(SCH == 1 ? a.wh : a.wb) + ((size_t)(ct * (WIDE ? 8 : 4) + cwave) * a.nsl) * WSL + lane;
 #ifndef TRACE_BF3_WPF
 #define TRACE_BF3_WPF 1           // weight slices in flight ahead of the one being multiplied
 #endif
@@ -501,7 +505,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #ifndef TRACE_BF3_EPI_REGS
 #define TRACE_BF3_EPI_REGS 0      // forward GroupNorm / Mish on the accumulators (conv_epilogue_fwd_rows)
 #endif
-  if constexpr (TRACE_BF3_EPI_REGS && NW == 4) {
+  if constexpr (TRACE_BF3_EPI_REGS && NW == 4 && !WIDE) {
     if (!a.gnb) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0, oscale); return; }
   }
 #ifdef TRACE_EXP_NOEPI
@@ -515,7 +519,14 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
     return;
   }
 #endif
-  conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw, oscale);
+  if constexpr (WIDE) {
+    // the two 64-channel halves go through the same output tile one after the other: waves 4 h .. 4 h + 3 drop
+    // their accumulators, all eight waves run the passes
+    conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, 0, wave < 4 ? NACC : 0, oscale);
+    conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0 + 64, 0, wave >= 4 ? NACC : 0, oscale);
+  } else {
+    conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw, oscale);
+  }
 }
 
 // workgroup id -> (row block, column tile): the ncol column tiles of one row block get ids of the same residue
@@ -527,6 +538,57 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   const int bid = blockIdx.x;
   conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS>(a, (bid / (8 * ncol)) * 8 + (bid & 7),
                                                                        (bid >> 3) % ncol);
+}
+
+// 8-wave workgroups of 128 output channels, one per CU (fp16 scheme): the activations of a row block are staged
+// and split by half as many workgroups.
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int CHN>
+__global__ __launch_bounds__(512, 2) void conv_wide_kernel(ConvArgs a) {
+  const int ncol = a.cout >> 7;
+  const int bid = blockIdx.x;
+  conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, false, 1, 8, 2, CHN, 1, true>(a, (bid / (8 * ncol)) * 8 + (bid & 7),
+                                                                        (bid >> 3) % ncol);
+}
+
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int CHN>
+int launch_conv_wide(const ConvArgs& a, hipStream_t st) {
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, 8, CHN, 1, true>;
+  if (a.rows <= 0) return TRACE_OK;
+  auto ok128 = [&](const float* p, int tstride, int coff) {
+    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 && (coff * L_OUT) % 4 == 0 &&
+                            (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
+  };
+  TRACE_REQUIRE(a.wh && a.in_amax && (a.cin2 == 0 || (a.in2 && a.in2_amax && UP == 1 && a.in2_tstride % 4 == 0 &&
+                                                       (size_t)(a.rows + TB) * a.in2_tstride * sizeof(float) < 0xffffffffull)) &&
+                    a.cout % 128 == 0 && a.cin % CHN == 0 && a.cin2 % CHN == 0 && a.nsl == TAPS * a.cin / 32 + a.cin2 / 32 &&
+                    (reinterpret_cast<uintptr_t>(a.in) & 3) == 0 &&
+                    (size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull &&
+                    ok128(a.out, a.out_tstride, a.out_coff) && ok128(a.res, a.res_tstride, a.res_coff) &&
+                    ok128(a.res2, a.res2_tstride, a.res2_coff) && ok128(a.ysave, a.cout * L_OUT, 0) &&
+                    ok128(a.out_raw, a.raw_tstride, a.raw_coff) && (!a.pc || a.pt) && !a.outp && !a.rawp,
+                "conv wide: bad arguments (cin=%d cin2=%d cout=%d nsl=%d)", a.cin, a.cin2, a.cout, a.nsl);
+  TRACE_REQUIRE(!a.gnb || (!a.gn && !a.pc && !a.ysave && a.gb_y && a.gb_stats && a.gb_gamma && a.gb_beta &&
+                           a.gb_cg > 0 && (a.gb_cg & (a.gb_cg - 1)) == 0 && a.gb_cg <= 64 && a.gb_cmax % 64 == 0 &&
+                           a.gb_cmax <= a.gb_c && (reinterpret_cast<uintptr_t>(a.gb_y) & 15) == 0),
+                "conv wide: bad GroupNorm-backward epilogue arguments");
+  TRACE_REQUIRE(!a.gn || (a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64), "conv: group size %d", a.cg);
+  constexpr size_t lds_bytes = (size_t)2 * G::PLANE > G::EPI_BYTES ? (size_t)2 * G::PLANE : G::EPI_BYTES;
+  static_assert(lds_bytes <= 160 * 1024, "conv wide: LDS");
+  static unsigned long long attr_done = 0;
+  if (first_launch_on_device(&attr_done)) {
+    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wide_kernel<L_OUT, UP, TAPS, PADL, TB, CHN>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  }
+  const int nrb = (a.rows + TB - 1) / TB;
+  dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 128));
+  const bool prof = prof_active();
+  if (prof) prof_pre(st);
+  hipLaunchKernelGGL((conv_wide_kernel<L_OUT, UP, TAPS, PADL, TB, CHN>), grid, dim3(512), lds_bytes, st, a);
+  if (prof) {
+    const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
+    prof_post(st, fl, fl * 3.0 / PEAK_MFMA16_FLOPS);
+  }
+  return launch_status("conv_wide_kernel");
 }
 
 // A residual block's first k5 conv (a) and its 1x1 residual conv (b) read the same input: one launch, the column
@@ -696,6 +758,13 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
 #ifndef TRACE_F16_CH
 #define TRACE_F16_CH 64           // channels per chunk of the full-chip fp16 launches with more than one tap (32 / 64)
 #endif
+    if constexpr (TAPS > 1) {
+      static const int wide = getenv("TRACE_F16_WIDE") ? atoi(getenv("TRACE_F16_WIDE")) : 0;   // 1: 64-, 2: 32-channel chunks
+      if (wide && a.cout % 128 == 0 && a.cin % 64 == 0 && a.cin2 % 64 == 0 && wgs > 1024) {
+        if (wide == 2) return launch_conv_wide<L_OUT, UP, TAPS, PADL, TB, 32>(a, st);
+        return launch_conv_wide<L_OUT, UP, TAPS, PADL, TB, 64>(a, st);
+      }
+    }
     if constexpr (TRACE_F16_CH == 64 && TAPS > 1) {
       if (a.cin % 64 == 0 && a.cin2 % 64 == 0)
         return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_NW, TRACE_BF3_WGS * TRACE_BF3_NW / 4, 64>(a, st);
