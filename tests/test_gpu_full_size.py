@@ -449,3 +449,56 @@ def test_fp16_pair_convs_agree_with_the_bf16_triple_convs(full):
             assert eg < 2e-5, eg
     finally:
         L.trace_conv_scheme(prev)
+
+
+def test_fp16_pair_convs_on_edge_inputs(full):
+    """Edge cases of the operand scales: a handful of rows (one partial group of 16), an all-zero incoming gradient
+    (amax 0: the scale is clamped, the result is exactly zero), one trajectory with a zero gradient among non-zero
+    ones, and gradients at the ends of the fp32 range (the head's per-trajectory power of two keeps them finite)."""
+    from trace_amd import _cabi
+    f = full
+    s, cfg, N = f["s"], f["cfg"], f["N"]
+    L = _cabi.lib()
+    x = f["x0"].to(DEV)
+    aux = s.get_aux_info({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in f["batch"].items()}, True)
+    _, _, x_in, _ = s.denoise(x, 60, aux, N, w=0.5, save=False)
+    cond_rows = torch.cat([aux["cond_feat"], aux["non_cond_feat"]], 0).contiguous()
+    table = torch.empty(cond_rows.shape[0], s.cond_width, device=DEV)
+    _cabi.check(L.trace_unet_cond_table(s._unet, cond_rows.data_ptr(), cond_rows.shape[0], table.data_ptr(), None))
+    prev = L.trace_conv_scheme(-1)
+
+    def run(R, gpred, mode):
+        L.trace_conv_scheme(mode)
+        ws_bytes = L.trace_unet_workspace_bytes(s._unet, R, 1)
+        ws = torch.zeros(ws_bytes // 4, dtype=torch.int32, device=DEV)
+        pred = torch.zeros(R, cfg.horizon, 2, device=DEV)
+        gx = torch.full((R, cfg.horizon, 2), float("nan"), device=DEV)
+        _cabi.check(L.trace_unet_forward(s._unet, x_in.data_ptr(), table.data_ptr(), N, 60, R, pred.data_ptr(),
+                                         ws.data_ptr(), ws_bytes, 1, None), "trace_unet_forward")
+        _cabi.check(L.trace_unet_backward_input(s._unet, gpred.data_ptr(), R, gx.data_ptr(), ws.data_ptr(),
+                                                ws_bytes, None), "trace_unet_backward_input")
+        torch.cuda.synchronize()
+        return pred, gx
+
+    try:
+        g = torch.Generator().manual_seed(41)
+        for R in (7, 16, 33):
+            gp = torch.randn(R, cfg.horizon, 2, generator=g).to(DEV)
+            (p0, g0), (p1, g1) = run(R, gp, 0), run(R, gp, 1)
+            assert float((p1 - p0).abs().max() / p0.abs().max()) < 5e-6
+            assert float(((g1 - g0).abs().amax((1, 2)) / g0.abs().amax((1, 2))).max()) < 2e-5
+        R = 48
+        zero = torch.zeros(R, cfg.horizon, 2, device=DEV)
+        _, gz = run(R, zero, 1)
+        assert bool((gz == 0).all())                                     # exactly zero, not NaN
+        gp = torch.randn(R, cfg.horizon, 2, generator=g).to(DEV)
+        gp[5] = 0.0                                                      # a trajectory without any guidance gradient
+        gp[6] *= 1e30                                                    # ... next to one near the top of the range
+        gp[7] *= 1e-30                                                   # ... and one near the bottom
+        (_, g0), (_, g1) = run(R, gp, 0), run(R, gp, 1)
+        assert bool((g1[5] == 0).all()) and bool(torch.isfinite(g1).all())
+        rel = (g1 - g0).abs().amax((1, 2)) / g0.abs().amax((1, 2)).clamp_min(1e-45)
+        rel[5] = 0.0
+        assert float(rel.max()) < 2e-5, rel
+    finally:
+        L.trace_conv_scheme(prev)
