@@ -74,7 +74,7 @@ def test_oriented_box_overlap_against_brute_force():
     pos = rng.uniform(-8, 8, (n, 2))
     yaw = rng.uniform(-np.pi, np.pi, n)
     ext = np.stack([rng.uniform(1.0, 5.0, n), rng.uniform(0.6, 2.2, n)], -1)
-    hit = boxes_intersect(torch.from_numpy(pos), torch.from_numpy(yaw), torch.from_numpy(ext)).numpy()
+    hit = np.asarray(boxes_intersect(torch.from_numpy(pos), torch.from_numpy(yaw), torch.from_numpy(ext)))
     cor = []
     for i in range(n):
         c, s = np.cos(yaw[i]), np.sin(yaw[i])
