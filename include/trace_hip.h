@@ -82,7 +82,10 @@ int64_t trace_unet_workspace_bytes(const trace_unet* u, int rows, int save);
  *   step   diffusion step t (same for all rows, tbsim/models/trace.py:738)
  *   pred   (rows, horizon, 2)
  * With classifier-free guidance the caller stacks conditional and unconditional rows
- * (rows = 2M) so both passes of tbsim/models/trace.py:572,588 run as one call. */
+ * (rows = 2M) so both passes of tbsim/models/trace.py:572,588 run as one call.
+ * Calls of 4096 rows and more launch half of their rows on a second stream owned by `u` (joined back
+ * into `stream` before the call returns control of it; not under stream capture): one call at a
+ * time per trace_unet. */
 int trace_unet_forward(trace_unet* u, const float* x_in, const float* cond_table,
                        int rows_per_cond, int step, int rows, float* pred, void* workspace,
                        int64_t workspace_bytes, int save, void* stream);
