@@ -349,8 +349,8 @@ struct trace_unet {
   std::vector<int> buf_twin;      // id of the buffer holding the pre-split bf16 planes of this one, or -1
   void* zero_cell = nullptr;      // 16 zero bytes (halo source of the plane staging)
   // second stream + fork / join events: large calls run the two halves of their rows side by side (run_split)
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
 
   // planes: the activation is a conv input -> a twin buffer of 3 bf16 planes (6 bytes per element)
   int new_buf(int floats, bool save_only, bool planes = false) {
@@ -605,8 +605,10 @@ extern "C" void trace_unet_destroy(trace_unet* u) {
   if (!u) return;
   for (void* p : u->allocs) (void)hipFree(p);
   if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
-  if (u->ev_join) (void)hipEventDestroy(u->ev_join);
-  if (u->side) (void)hipStreamDestroy(u->side);
+  for (int i = 0; i < 3; ++i) {
+    if (u->ev_join[i]) (void)hipEventDestroy(u->ev_join[i]);
+    if (u->side[i]) (void)hipStreamDestroy(u->side[i]);
+  }
   delete u;
 }
 
@@ -834,10 +836,12 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
     u->allocs.push_back(z);
     u->zero_cell = z;
   }
-  if (hipStreamCreateWithFlags(&u->side, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming) != hipSuccess ||
-      hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming) != hipSuccess) {
-    set_error("trace_unet_create: cannot create the side stream / events");
+  bool side_ok = hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming) == hipSuccess;
+  for (int i = 0; i < 3 && side_ok; ++i)
+    side_ok = hipStreamCreateWithFlags(&u->side[i], hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&u->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  if (!side_ok) {
+    set_error("trace_unet_create: cannot create the side streams / events");
     trace_unet_destroy(u);
     return TRACE_EHIP;
   }
@@ -1130,21 +1134,30 @@ int run_gn_bwd(const View& da, const float* y, const float* stats, const float* 
 template <typename F>
 int run_split(trace_unet* u, int rows, int quantum, hipStream_t st, F&& part) {
   static const int split_min = getenv("TRACE_UNET_SPLIT_MIN") ? atoi(getenv("TRACE_UNET_SPLIT_MIN")) : 4096;
-  const int r1 = quantum > 0 ? (rows / 2 / quantum) * quantum : 0;
-  if (split_min <= 0 || rows < split_min || r1 <= 0 || r1 >= rows || prof_active() || prof_stamping() || !u->side)
+  static const int nparts_env = getenv("TRACE_UNET_SPLIT_PARTS") ? atoi(getenv("TRACE_UNET_SPLIT_PARTS")) : 2;
+  const int nparts = nparts_env < 2 ? 2 : (nparts_env > 4 ? 4 : nparts_env);
+  const int per = quantum > 0 ? (rows / nparts / quantum) * quantum : 0;
+  if (split_min <= 0 || rows < split_min || per <= 0 || prof_active() || prof_stamping() || !u->side[0])
     return part(0, rows, st);
   // not under stream capture: a replayed graph ran its two branches slower than one (4435 against 4730 trajectories/s)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return part(0, rows, st);
   TRACE_CHECK_HIP(hipEventRecord(u->ev_fork, st));
-  TRACE_CHECK_HIP(hipStreamWaitEvent(u->side, u->ev_fork, 0));
-  int rc = part(0, r1, st);
-  const int rc2 = part(r1, rows - r1, u->side);
-  // join even after an error, so that a capturing stream is left in a consistent state
-  if (hipEventRecord(u->ev_join, u->side) != hipSuccess || hipStreamWaitEvent(st, u->ev_join, 0) != hipSuccess) {
-    if (!rc && !rc2) { set_error("run_split: join failed"); rc = TRACE_EHIP; }
+  for (int i = 0; i + 1 < nparts; ++i) TRACE_CHECK_HIP(hipStreamWaitEvent(u->side[i], u->ev_fork, 0));
+  int rc = part(0, per, st);
+  for (int i = 1; i < nparts; ++i) {
+    const int r0 = i * per;
+    const int rc2 = part(r0, i + 1 == nparts ? rows - r0 : per, u->side[i - 1]);
+    if (!rc) rc = rc2;
   }
-  return rc ? rc : rc2;
+  // join even after an error, so that no stream is left running behind the caller's back
+  for (int i = 0; i + 1 < nparts; ++i) {
+    if (hipEventRecord(u->ev_join[i], u->side[i]) != hipSuccess ||
+        hipStreamWaitEvent(st, u->ev_join[i], 0) != hipSuccess) {
+      if (!rc) { set_error("run_split: join failed"); rc = TRACE_EHIP; }
+    }
+  }
+  return rc;
 }
 
 static int lcm_int(int a, int b) {
