@@ -506,7 +506,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #define TRACE_BF3_EPI_REGS 0      // forward GroupNorm / Mish on the accumulators (conv_epilogue_fwd_rows)
 #endif
   if constexpr (TRACE_BF3_EPI_REGS && NW == 4 && !WIDE) {
-    if (!a.gnb) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0, oscale); return; }
+    if (!a.gnb && !a.head_pred) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0, oscale); return; }
   }
 #ifdef TRACE_EXP_NOEPI
   if (a.rows >= 0) {        // timing-only build: the accumulators stay live, the epilogue never runs
@@ -774,7 +774,7 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
   static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
   // full-chip launches of the multi-tap convs: the persistent wave-specialised kernel (conv_ws_kernels.h)
   if constexpr (TAPS > 1) {
-    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > small_max && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp)
+    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > small_max && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp && !a.head_pred)
       return launch_conv_ws<L_OUT, UP, TAPS, PADL, TB>(a, st);
   }
   if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max)

@@ -109,6 +109,11 @@ struct ConvArgs {
   int wexp;
   const unsigned* in_amax;   // max |in| per 16 trajectories (index row / 16), or null
   const unsigned* in2_amax;
+  // Fused head (final block only, cout == 64): pred[row][l][o] = head_b[o] + sum_c head_w[o][c] out[row][c][l], formed
+  // from the finished output tile in LDS; `out` may then be null (the activation itself is never read again)
+  const float* head_w;       // [2][64] or null
+  const float* head_b;       // [2]
+  float* head_pred;          // [rows][L_OUT][2]
   unsigned* out_amax;        // where this launch's epilogue records max |out| (null: not recorded)
   unsigned* raw_amax;        // ... and max |out_raw| of the GroupNorm-backward epilogue
 };
@@ -685,6 +690,24 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
   if (has_tab) __syncthreads();
   TRACE_STAMP(9);
 
+  // Fused head: the tile holds the finished activation (no residual on this layer); one (trajectory, position) per
+  // thread, the 64 channels in the order and with the FMAs of head_fwd_kernel (same bits)
+  if (a.head_pred) {
+    for (int idx = tid; idx < R; idx += NTH) {
+      const int tr = idx / L_OUT, l = idx - tr * L_OUT;
+      const float* col = lds + tr * TILE + l;
+      float p0 = a.head_b[0], p1 = a.head_b[1];
+#pragma unroll 16
+      for (int ch = 0; ch < 64; ++ch) {
+        const float v = col[ch * L_OUT];
+        p0 = fmaf(a.head_w[ch], v, p0);
+        p1 = fmaf(a.head_w[64 + ch], v, p1);
+      }
+      if (traj0 + tr < a.rows)
+        *reinterpret_cast<float2*>(a.head_pred + ((size_t)(traj0 + tr) * L_OUT + l) * 2) = float2{p0, p1};
+    }
+    if (!a.out) { TRACE_STAMP(11); return; }
+  }
   // E2: flat pass -- + residual(s), store; 4 consecutive outputs per access
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
       a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);

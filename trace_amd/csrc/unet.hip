@@ -38,6 +38,11 @@ int conv_scheme(int mode) {
   return prev;
 }
 
+bool force_fp32_convs() {
+  static const bool v = [] { const char* e = getenv("TRACE_CONV_FP32"); return e && e[0] == '1'; }();
+  return v;
+}
+
 bool prof_stamping() {
 #ifdef TRACE_CONV_STAMPS
   return true;       // diagnostic builds number the conv launches: keep them one kernel each
@@ -1300,13 +1305,22 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
   View up1 = whole(u->b_up1, d0, H);
   RUN(run_conv(K_UP_F, H, conv_args(bout[11], u->up_f[1], u->up_bias[1], up1, rows), st));
   View f = whole(u->b_f, d0, H);
+  bool head_fused = false;
   {
     ConvArgs a = conv_args(up1, u->final_f, u->fb, f, rows);
     a.gn = 1; a.cg = d0 / 8; a.gamma = u->fg; a.beta = u->fbe;
     if (save) { a.ysave = buf(u->b_yf); a.stats = buf(u->b_sf); }
+    // the 1x1 head rides in this conv's epilogue (the whole 64-channel activation of a trajectory is in the
+    // workgroup's tile) and the activation itself, which nothing else reads, is not written
+    static const bool no_fuse = getenv("TRACE_NO_HEAD_FUSE") != nullptr;
+    head_fused = !no_fuse && d0 == 64 && a.wb && !force_fp32_convs();
+    if (head_fused) {
+      a.head_w = u->head_w; a.head_b = u->head_b; a.head_pred = pred;
+      a.out = nullptr; a.out_amax = nullptr;
+    }
     RUN(run_conv(K_CONV5, H, a, st));
   }
-  {
+  if (!head_fused) {
     TRACE_REQUIRE(H % 4 == 0, "head: horizon %d not a multiple of 4", H);
     int n = rows * (H / 4);
     hipLaunchKernelGGL(head_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, st, f.p, u->head_w,
