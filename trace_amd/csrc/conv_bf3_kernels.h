@@ -100,9 +100,14 @@ struct Bf3Geom {
 // CHN = channels per chunk (LDS image / barrier pair): 32, or 64 for the fp16 scheme (half the chunk switches; the
 //       two k-slices of a tap are multiplied one after the other, the next chunk's loads issued half in each).
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1, bool WIDE = false>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1, bool WIDE = false,
+          bool FROM_TILE = false>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, const int ct) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS, WIDE>;
+  // FROM_TILE: the (single, 64-channel) input chunk is the finished activation a previous conv of the same workgroup
+  // left in the LDS output tile ([trajectory][channel][position] fp32); its scale comes from the tile's own maximum
+  static_assert(!FROM_TILE || (SCH == 1 && CHN == 64 && UP == 1 && IS == 1 && NW == 4 && !WIDE && !PLN),
+                "tile-staged input: fp16 scheme, one 64-channel chunk, stride 1");
   static_assert(!WIDE || (SCH == 1 && !PLN), "wide workgroups: fp16 scheme");
   static_assert(IS == 1 || !PLN, "stride 2: register staging only");
   static_assert(SCH == 0 || (SCH == 1 && !PLN), "two schemes; the plane tensors are bf16 x 3 only");
@@ -138,7 +143,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   // the largest |value| of their group of 16 (both K sources share the accumulators, hence one scale), so the
   // scaled maximum lies in [2^14, 2^15); the accumulators are scaled back by 2^-(14 - E) 2^-wexp
   float ascale = 1.f, oscale = 1.f;
-  if constexpr (SCH == 1) {
+  if constexpr (SCH == 1 && !FROM_TILE) {
     unsigned am = __hip_atomic_load(a.in_amax + (traj0 >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.cin2) {
       const unsigned am2 = __hip_atomic_load(a.in2_amax + (traj0 >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -276,9 +281,35 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
     }
   };
 
-  if constexpr (!PLN) {
+  if constexpr (FROM_TILE) {
+    float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < NUT; ++j) stage_load_unit(0, j);
+    for (int j = 0; j < NUT; ++j) {
+      const bool live = (NU % NTH == 0) || (tid + NTH * j < NU);
+      const float* src = lds + (live ? (spk[j] >> 20) * (64 * L_OUT) + (spk[j] & 0xfffffu) : 0u);
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        stg[j][jj] = src[jj * L_OUT];
+        m = fmaxf(m, fabsf(stg[j][jj]));
+      }
+    }
+    m = wave_max_nonneg(m);
+    __syncthreads();                           // every thread has its part of the tile in registers
+    if (lane == 0) lds[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
+    int ef = (int)(__builtin_bit_cast(unsigned, m) >> 23);
+    ef = ef < 87 ? 87 : (ef > 167 ? 167 : ef);
+    const int sf = 268 - ef;
+    ascale = __builtin_bit_cast(float, (unsigned)sf << 23);
+    oscale = __builtin_bit_cast(float, (unsigned)(254 - sf - a.wexp) << 23);
+    __syncthreads();                           // the scale is read before the image overwrites it
+  }
+  if constexpr (!PLN) {
+    if constexpr (!FROM_TILE) {
+#pragma unroll
+      for (int j = 0; j < NUT; ++j) stage_load_unit(0, j);
+    }
     // halo / zero-stuffing positions are written once; data positions are rewritten by every chunk
     if constexpr (UP == 1 && TAPS == 1 && IS == 1) {
     } else if constexpr (UP == 1) {
@@ -589,6 +620,57 @@ int launch_conv_wide(const ConvArgs& a, hipStream_t st) {
     prof_post(st, fl, fl * 3.0 / PEAK_MFMA16_FLOPS);
   }
   return launch_status("conv_wide_kernel");
+}
+
+// The two k5 convs of a residual block whose 64 output channels fit one workgroup tile (the L = 52 levels): conv 1's
+// finished activation (GroupNorm + Mish + condition) stays in the LDS output tile and conv 2 stages its single
+// 64-channel chunk from there -- it is never written to or read from HBM (272 MB per block at 10240 rows).  The
+// saved raw outputs, the statistics and conv 2's residual / output are as in the separate launches; conv 2's operand
+// scale comes from the workgroup's own tile instead of the 16-trajectory group (also an exact power of two).
+template <int L_OUT, int TB>
+__global__ __launch_bounds__(256, 2) void conv_block_fwd_kernel(ConvArgs a, ConvArgs b) {
+  const int bid = blockIdx.x;
+  if (bid * TB >= a.rows) return;
+  conv_bf3_body<L_OUT, 1, 5, 2, TB, false, 1, 4, 2, 64, 1, false, false>(a, bid, 0);
+  conv_bf3_body<L_OUT, 1, 5, 2, TB, false, 1, 4, 2, 64, 1, false, true>(b, bid, 0);
+}
+
+template <int L_OUT, int TB>
+int launch_conv_block_fwd(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
+  using G = Bf3Geom<L_OUT, 1, 5, 2, TB, 4, 64, 1>;
+  if (a.rows <= 0) return TRACE_OK;
+  auto ok128 = [&](const float* p, int tstride, int coff) {
+    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 && (coff * L_OUT) % 4 == 0 &&
+                            (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
+  };
+  TRACE_REQUIRE(a.rows == b.rows && a.cout == 64 && b.cout == 64 && b.cin == 64 && a.cin % 64 == 0 && a.cin2 == 0 &&
+                    b.cin2 == 0 && a.wh && b.wh && a.in_amax && a.nsl == 5 * a.cin / 32 && b.nsl == 10 && a.keep_tile &&
+                    !a.out && a.gn && b.gn && !a.gnb && !b.gnb && !a.res && !a.res2 && !a.head_pred && !b.keep_tile &&
+                    a.wexp >= -10 && a.wexp <= 40 && b.wexp >= -10 && b.wexp <= 40,
+                "conv block: bad geometry (cin=%d/%d cout=%d/%d)", a.cin, b.cin, a.cout, b.cout);
+  TRACE_REQUIRE((reinterpret_cast<uintptr_t>(a.in) & 3) == 0 &&
+                    (size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull &&
+                    ok128(a.ysave, 64 * L_OUT, 0) && ok128(b.ysave, 64 * L_OUT, 0) && ok128(b.out, b.out_tstride, b.out_coff) &&
+                    ok128(b.res, b.res_tstride, b.res_coff) && ok128(b.res2, b.res2_tstride, b.res2_coff) &&
+                    (!a.pc || a.pt) && (!b.pc || b.pt) && a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64 &&
+                    b.cg > 0 && (b.cg & (b.cg - 1)) == 0 && b.cg <= 64,
+                "conv block: tensors must be 16-byte aligned per trajectory tile and below 4 GiB");
+  constexpr size_t lds_bytes = (size_t)2 * G::PLANE > G::EPI_BYTES ? (size_t)2 * G::PLANE : G::EPI_BYTES;
+  static_assert(lds_bytes <= 80 * 1024, "conv block: LDS per workgroup too large for two per CU");
+  static unsigned long long attr_done = 0;
+  if (first_launch_on_device(&attr_done)) {
+    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_block_fwd_kernel<L_OUT, TB>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+  }
+  dim3 grid((a.rows + TB - 1) / TB);
+  const bool prof = prof_active();
+  if (prof) prof_pre(st);
+  hipLaunchKernelGGL((conv_block_fwd_kernel<L_OUT, TB>), grid, dim3(256), lds_bytes, st, a, b);
+  if (prof) {
+    const double fl = 2.0 * (a.alg_macs_per_pos + b.alg_macs_per_pos) * (double)a.rows * L_OUT;
+    prof_post(st, fl, fl * 3.0 / PEAK_MFMA16_FLOPS);
+  }
+  return launch_status("conv_block_fwd_kernel");
 }
 
 // A residual block's first k5 conv (a) and its 1x1 residual conv (b) read the same input: one launch, the column

@@ -111,6 +111,9 @@ struct ConvArgs {
   const unsigned* in2_amax;
   // Fused head (final block only, cout == 64): pred[row][l][o] = head_b[o] + sum_c head_w[o][c] out[row][c][l], formed
   // from the finished output tile in LDS; `out` may then be null (the activation itself is never read again)
+  // keep_tile: the epilogue stops once the finished activation sits in the LDS output tile (statistics and the saved
+  // raw output are written as usual, `out` is not): conv_block_fwd_kernel stages the block's second conv from it
+  int keep_tile;
   const float* head_w;       // [2][64] or null
   const float* head_b;       // [2]
   float* head_pred;          // [rows][L_OUT][2]
@@ -690,6 +693,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
   if (has_tab) __syncthreads();
   TRACE_STAMP(9);
 
+  if (a.keep_tile) return;
   // Fused head: the tile holds the finished activation (no residual on this layer); one (trajectory, position) per
   // thread, the 64 channels in the order and with the FMAs of head_fwd_kernel (same bits)
   if (a.head_pred) {

@@ -1278,11 +1278,27 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
       }
       if (!paired) RUN(run_conv(K_CONV1, b.L, ar, st));
     }
-    if (!paired) RUN(run_conv(K_CONV5, b.L, a, st));
     ConvArgs a2 = conv_args(h1, b.c2f, b.b2, bout[i], rows);
     a2.gn = 1; a2.cg = b.cout / 8; a2.gamma = b.g2; a2.beta = b.be2;
     set_res(a2, r);
     if (save) { a2.ysave = buf(u->b_y2[i]); a2.stats = buf(u->b_s2[i]); }
+    // blocks of 64 output channels (= one workgroup tile; L = 52 and the last two of L = 26): both k5 convs in one launch, the activation between
+    // them stays in LDS (conv_block_fwd_kernel).  Measured: the fused launch takes 249 us against 2 x 142 us, yet a
+    // pass does not get faster (10.06 against 10.00 ms, A/B inside one call; 256 VGPRs + 108 B of scratch): opt-in,
+    // TRACE_BLOCK_FUSE=1
+    static const bool no_block = getenv("TRACE_BLOCK_FUSE") == nullptr;
+    if (!paired && !no_block && (b.L == 52 || b.L == 26) && b.cout == 64 && conv_scheme(-1) && a.wh && a2.wh && a.in_amax &&
+        a.cin_b == a.cin && a.cin % 64 == 0 && rows >= 2048 && !prof_stamping() && !force_fp32_convs()) {
+      ConvArgs a1 = a;
+      a1.cin = a1.cin_b; a2.cin = a2.cin_b;
+      a1.zero_cell = a2.zero_cell = t_zero_cell;
+      a1.out = nullptr; a1.out_amax = nullptr; a1.keep_tile = 1;
+      a2.in_amax = nullptr;                       // conv 2 scales by its own tile's maximum
+      if (b.L == 52) RUN((launch_conv_block_fwd<52, 4>(a1, a2, st)));
+      else RUN((launch_conv_block_fwd<26, 8>(a1, a2, st)));
+      return TRACE_OK;
+    }
+    if (!paired) RUN(run_conv(K_CONV5, b.L, a, st));
     RUN(run_conv(K_CONV5, b.L, a2, st));
     return TRACE_OK;
   };
