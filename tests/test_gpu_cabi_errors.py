@@ -92,7 +92,8 @@ def test_profile_hooks_count_conv_launches(sampler):
                                 ws.data_ptr(), need, 0, None) == 0
     ms, nl, fl = C.c_double(), C.c_int64(), C.c_double()
     assert L.trace_profile_end(C.byref(ms), C.byref(nl), C.byref(fl)) == 0
-    assert nl.value == 34 and ms.value > 0
+    # 34 convs; at this size the k5 conv and the 1x1 residual conv of blocks 2, 4, 8, 10 share a launch
+    assert nl.value == 30 and ms.value > 0
     # SURVEY.md 8d counts 60,288,512 MACs per trajectory per denoiser forward.  Of these the conv
     # kernels do all but: the 1x1 head (2*64*52, its own kernel), the 12 per-block cond/time
     # Linears (1792 * 288, tabulated once per call / at create time) and the time MLP (2*32*128).

@@ -1262,12 +1262,15 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
       r = whole(u->b_res[i], b.cout, b.L);
       ConvArgs ar = conv_args(bin[i], b.rf, b.br, r, rows);
       // the k5 conv and the 1x1 residual conv of the block in one launch (fp16 scheme, full-chip launches)
-      // Measured (A/B inside one call): 10.46 ms per pass paired against 10.39 separate -- no gain, the 1x1
-      // workgroups only trade places with k5 workgroups on the same issue-bound CUs.  Opt-in: TRACE_CONV_PAIR=1.
-      static const bool no_pair = getenv("TRACE_CONV_PAIR") == nullptr;
-      const long wgs = (long)((rows + 3) / 4) * (b.cout / 64);
-      if (!no_pair && conv_scheme(-1) && a.wh && ar.wh && a.in_amax && a.cin_b == a.cin && a.cin % 64 == 0 &&
-          wgs > 1024 && !prof_stamping()) {
+      // Measured (A/B inside one call).  Full-chip launches: 10.46 ms per pass paired against 10.39 separate -- no
+      // gain, the 1x1 workgroups only trade places with k5 workgroups on the same issue-bound CUs.  Small launches
+      // (cfg1, 320 rows, one workgroup per CU at most): 79.9 ms per 100-step call against 87.5 -- four launches
+      // less per step on a latency-bound chain.  Default: small launches only (TRACE_CONV_PAIR = 0 none, 1 large,
+      // 2 small, 3 all).
+      static const int pair_mode = getenv("TRACE_CONV_PAIR") ? atoi(getenv("TRACE_CONV_PAIR")) : 2;
+      const bool small = rows < 2048;
+      if ((pair_mode & (small ? 2 : 1)) && conv_scheme(-1) && a.wh && ar.wh && a.in_amax && a.cin_b == a.cin &&
+          a.cin % 64 == 0 && !prof_stamping()) {
         ConvArgs a1 = a, a2 = ar;
         a1.cin = a1.cin_b; a2.cin = a2.cin_b;
         a1.zero_cell = a2.zero_cell = t_zero_cell;
@@ -1286,9 +1289,9 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
     // them stays in LDS (conv_block_fwd_kernel).  Measured: the fused launch takes 249 us against 2 x 142 us, yet a
     // pass does not get faster (10.06 against 10.00 ms, A/B inside one call; 256 VGPRs + 108 B of scratch): opt-in,
     // TRACE_BLOCK_FUSE=1
-    static const bool no_block = getenv("TRACE_BLOCK_FUSE") == nullptr;
-    if (!paired && !no_block && (b.L == 52 || b.L == 26) && b.cout == 64 && conv_scheme(-1) && a.wh && a2.wh && a.in_amax &&
-        a.cin_b == a.cin && a.cin % 64 == 0 && rows >= 2048 && !prof_stamping() && !force_fp32_convs()) {
+    static const int block_mode = getenv("TRACE_BLOCK_FUSE") ? atoi(getenv("TRACE_BLOCK_FUSE")) : 0;  // 1: large, 2: small, 3: all
+    if (!paired && (block_mode & (rows < 2048 ? 2 : 1)) && (b.L == 52 || b.L == 26) && b.cout == 64 && conv_scheme(-1) &&
+        a.wh && a2.wh && a.in_amax && a.cin_b == a.cin && a.cin % 64 == 0 && !prof_stamping() && !force_fp32_convs()) {
       ConvArgs a1 = a;
       a1.cin = a1.cin_b; a2.cin = a2.cin_b;
       a1.zero_cell = a2.zero_cell = t_zero_cell;
