@@ -81,6 +81,9 @@ struct Bf3Geom {
   static_assert(PLANE + NOCT * SUB < 131072, "plane offsets stay small");
 };
 
+#ifndef TRACE_BF3_WPF
+#define TRACE_BF3_WPF 1           // weight slices in flight ahead of the one being multiplied (full-chip launches)
+#endif
 #ifndef TRACE_BF3_WGS
 #define TRACE_BF3_WGS 2           // resident workgroups per CU the register budget is sized for
 #endif
@@ -101,7 +104,7 @@ struct Bf3Geom {
 //       two k-slices of a tap are multiplied one after the other, the next chunk's loads issued half in each).
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
           int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1, bool WIDE = false,
-          bool FROM_TILE = false>
+          bool FROM_TILE = false, int WPF = TRACE_BF3_WPF>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, const int ct) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS, WIDE>;
   // FROM_TILE: the (single, 64-channel) input chunk is the finished activation a previous conv of the same workgroup
@@ -349,16 +352,13 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
   constexpr int WSL = 64 * NPL;                  // fragments per slice
   const bf16x8* wp = reinterpret_cast<const bf16x8*>(SCH == 1 ? a.wh : a.wb) + ((size_t)(ct * (WIDE ? 8 : 4) + cwave) * a.nsl) * WSL + lane;
-#ifndef TRACE_BF3_WPF
-#define TRACE_BF3_WPF 1           // weight slices in flight ahead of the one being multiplied
-#endif
 #ifndef TRACE_BF3_NST
 #define TRACE_BF3_NST 4           // A-fragment register stages (prefetch distance + 1)
 #endif
   bf16x8 bn1[NPL], bn2[NPL];
 #pragma unroll
   for (int p = 0; p < NPL; ++p) bn1[p] = wp[64 * p];
-  if constexpr (TRACE_BF3_WPF >= 2) {
+  if constexpr (WPF >= 2) {
 #pragma unroll
     for (int p = 0; p < NPL; ++p) bn2[p] = a.nsl > 1 ? wp[WSL + 64 * p] : bn1[p];
   }
@@ -386,7 +386,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       if (n % NR == 0) {
-        if constexpr (TRACE_BF3_WPF >= 2) {
+        if constexpr (WPF >= 2) {
 #pragma unroll
           for (int p = 0; p < NPL; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
           ++sdone;
@@ -563,12 +563,13 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 // workgroup id -> (row block, column tile): the ncol column tiles of one row block get ids of the same residue
 // mod 8, 8 apart (same XCD, same time: see conv_gemm_kernel)
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1,
+          int WPF = TRACE_BF3_WPF>
 __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   const int ncol = a.cout >> 6;
   const int bid = blockIdx.x;
-  conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS>(a, (bid / (8 * ncol)) * 8 + (bid & 7),
-                                                                       (bid >> 3) % ncol);
+  conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS, false, false, WPF>(
+      a, (bid / (8 * ncol)) * 8 + (bid & 7), (bid >> 3) % ncol);
 }
 
 // 8-wave workgroups of 128 output channels, one per CU (fp16 scheme): the activations of a row block are staged
@@ -731,7 +732,8 @@ int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH = 0, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1>
+          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1,
+          int WPF = TRACE_BF3_WPF>
 int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS>;
   static_assert(CHN == 32 || NW == 4, "64-channel chunks: 4-wave workgroups");
@@ -784,7 +786,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   static unsigned long long attr_done = 0;      // one bit per device
   if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS>),
+        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS, WPF>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   }
   const int nrb = (a.rows + TB - 1) / TB;
@@ -794,7 +796,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
 #endif
   const bool prof = prof_active();
   if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS>), grid, dim3(G::NTH), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS, WPF>), grid, dim3(G::NTH), lds_bytes, st, a);
   if (prof) {
     const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
     prof_post(st, fl, fl * (SCH == 1 ? 3.0 : 6.0) / PEAK_MFMA16_FLOPS);
@@ -840,6 +842,11 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
 #ifndef TRACE_F16_CH
 #define TRACE_F16_CH 64           // channels per chunk of the full-chip fp16 launches with more than one tap (32 / 64)
 #endif
+    // launches of at most one workgroup per CU (cfg1) with two weight slices in flight and 32-channel chunks (the
+    // registers for it): measured slower, 83.6 against 79.9 ms per call -- opt-in (TRACE_F16_LONE_MAX = workgroups)
+    static const int lone_max = getenv("TRACE_F16_LONE_MAX") ? atoi(getenv("TRACE_F16_LONE_MAX")) : 0;
+    if (wgs <= lone_max)
+      return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_NW, TRACE_BF3_WGS * TRACE_BF3_NW / 4, 32, 1, 2>(a, st);
     if constexpr (TAPS > 1) {
       static const int wide = getenv("TRACE_F16_WIDE") ? atoi(getenv("TRACE_F16_WIDE")) : 0;   // 1: 64-, 2: 32-channel chunks
       if (wide && a.cout % 128 == 0 && a.cin % 64 == 0 && a.cin2 % 64 == 0 && wgs > 1024) {
@@ -853,10 +860,12 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
     }
     return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1>(a, st);
   }
-  static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 256;
+  // bf16-triple small launches: the 16-wave form won 120.7 -> 100.1 ms on cfg1 when every conv was a bf16-triple one;
+  // now only the first block and the conv behind the head are, and the 4-wave form is faster (78.2 against 79.9 ms)
+  static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 0;
   // full-chip launches of the multi-tap convs: the persistent wave-specialised kernel (conv_ws_kernels.h)
   if constexpr (TAPS > 1) {
-    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > small_max && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp && !a.head_pred)
+    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > 256 && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp && !a.head_pred)
       return launch_conv_ws<L_OUT, UP, TAPS, PADL, TB>(a, st);
   }
   if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max)
