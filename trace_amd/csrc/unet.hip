@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
       } else {
         up = db[e];
       }
-      float gz = up * mish_grad_f(z) * ga;
+      float gz = up * mish_grad_fast_f(z) * ga;      // as the fused epilogues (<= 2 ulp, hardware exp / rcp)
       gg[k] = gz;
       xh[k] = x;
       s1 += gz;
