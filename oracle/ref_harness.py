@@ -111,9 +111,12 @@ def load_reference():
             return None, self.grid_cond
 
     ref_trace.MapEncoder = PresetMapEncoder
+    # trace_helpers.MapGridDecoder (and base_models.Up / DoubleConv / ConvBlock under it) is pure torch: the
+    # decoder half of the map encoder is available from the reference itself (gen_golden_map_decoder.py)
     ns = types.SimpleNamespace(trace=ref_trace, helpers=ref_helpers, temporal=ref_temporal,
                                guidance=ref_guidance, geom=ref_geom,
-                               PresetMapEncoder=PresetMapEncoder)
+                               PresetMapEncoder=PresetMapEncoder,
+                               MapGridDecoder=ref_helpers.MapGridDecoder)
     _LOADED["ns"] = ns
     return ns
 

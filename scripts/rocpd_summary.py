@@ -23,6 +23,16 @@ def stats(path):
                                                           r[4], r[5], r[6], r[7], r[8], r[9]))
 
 
+def seq(path):
+    """every dispatch in start order: short kernel name, grid, duration (for launch-by-launch A/B of two builds)"""
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
+    gx = "grid_size_x" if "grid_size_x" in cols else ("grid_x" if "grid_x" in cols else "0")
+    rows = db.execute("select name, %s, duration, start from kernels order by start" % gx).fetchall()
+    for i, r in enumerate(rows):
+        print("%d,%s,%d,%d" % (i, r[0][:90].replace(",", ";"), r[1], r[2]))
+
+
 def pmc(path):
     db = sqlite3.connect(path)
     rows = db.execute(
@@ -34,4 +44,4 @@ def pmc(path):
 
 
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "seq": seq}[sys.argv[1]](sys.argv[2])

@@ -3,8 +3,9 @@ torch on the CPU: every built trace_conv2d shape with the fused scale / shift / 
 windows, the stem, max-pool, bilinear up-sampling and LayerNorm kernels, and the assembled encoder against the
 functional torch path and the independent nn.Module assembly of tests/test_map_encoder_cpu.py.
 
-PARITY UNPINNED against the reference's own encoder (torchvision absent): the checker here is
-torch's fp32 CPU implementation of the same layers.  Tolerances are fp32 round-off of K-long dot products:
+PARITY: the decoder half is pinned against the reference's own MapGridDecoder (tests/golden/map_decoder.npz,
+`test_hip_decoder_half_matches_the_reference_map_grid_decoder`); the ResNet-18 trunk is UNPINNED against the reference
+(torchvision absent): the checker there is torch's fp32 CPU implementation of the same layers.  Tolerances are fp32 round-off of K-long dot products:
 |got - want| <= 2e-5 * max|want| per layer, 3e-4 * max|want| after the 30 layers of the encoder."""
 import pytest
 import torch
@@ -178,6 +179,24 @@ def test_map_encoder_hip_matches_torch_cpu_and_module_assembly(cin, B):
     # the unconditional image (constant fill) encodes identically for every agent
     _, g2 = enc2(torch.ones_like(img) * 0.5)
     assert float((g2[0] - g2[1]).abs().max()) == 0.0
+
+
+def test_hip_decoder_half_matches_the_reference_map_grid_decoder():
+    """`MapEncoder.decode` on the library's kernels (conv2d / upsample / LayerNorm through the C ABI) against the
+    output the REFERENCE's MapGridDecoder gave for the same weights and features
+    (/root/reference/tbsim/models/trace_helpers.py:231-268, recorded by oracle/gen_golden_map_decoder.py), at the
+    tolerance the assembled-encoder test uses (3e-4 of the output's scale: 14 convs + LayerNorm of split-bf16 fp32)."""
+    from test_map_encoder_cpu import _decoder_fixture          # tests/ is on sys.path (pytest's rootdir mode)
+    from trace_amd.map_encoder import MapEncoder
+    sd, feats, want = _decoder_fixture()
+    enc = MapEncoder(sd, device=DEV, backend="hip")
+    got = enc.decode([f.to(DEV) for f in feats]).cpu()
+    assert got.shape == want.shape
+    err = float((got - want).abs().max())
+    assert err <= 3e-4 * float(want.abs().max()), err
+    # bit-reproducible, and independent of what the buffers held before
+    enc(torch.randn(2, 2, 224, 224, device=DEV))
+    assert torch.equal(enc.decode([f.to(DEV) for f in feats]).cpu(), got)
 
 
 def test_sampler_accepts_the_channels_last_grid_of_the_hip_encoder():

@@ -2,6 +2,8 @@
 independent nn.Module assembly of the same layers (torchvision-style ResNet-18 naming), loaded
 from the same state_dict.  PARITY UNPINNED against the reference itself: torchvision is absent, so
 the reference's MapEncoder cannot be instantiated here."""
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -137,3 +139,40 @@ def test_missing_weights_raise():
         assert "conv3.bias" in str(e)
     else:
         raise AssertionError("expected KeyError")
+
+
+# ---- the decoder half against the REFERENCE's own MapGridDecoder (tests/golden/map_decoder.npz) ----------------
+def _decoder_fixture():
+    """Weights / features rebuilt from their names (oracle/gen_golden_map_decoder.py), checked against the checksums
+    the generator recorded next to the reference's output."""
+    import numpy as np
+    from oracle.gen_golden_map_decoder import decoder_features, decoder_tensor
+    from trace_amd.map_encoder import map_encoder_shapes, random_map_encoder_state_dict
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "map_decoder.npz"))
+    shapes = map_encoder_shapes(2, 32)
+    sd = random_map_encoder_state_dict(2, 32, seed=3)          # trunk weights: unused by decode()
+    names = [str(n) for n in gold["names"]]
+    # the reference's decoder has exactly the tensors the product expects below `map_encoder.decoder.`
+    assert sorted("map_encoder.decoder." + n for n in names) == sorted(k for k in shapes if k.startswith("map_encoder.decoder."))
+    digest = 0.0
+    for n in names:
+        t = decoder_tensor(n, shapes["map_encoder.decoder." + n])
+        sd["map_encoder.decoder." + n] = t
+        digest += float(t.double().abs().sum())
+    feats = decoder_features(2)
+    assert abs(digest - float(gold["weight_abs_sum"])) <= 1e-9 * digest
+    fsum = sum(float(f.double().abs().sum()) for f in feats)
+    assert abs(fsum - float(gold["feat_abs_sum"])) <= 1e-9 * fsum
+    return sd, feats, torch.from_numpy(gold["out"])
+
+
+def test_decoder_half_reproduces_the_reference_map_grid_decoder():
+    """`MapEncoder.decode` (torch backend, CPU) against the output of the reference's MapGridDecoder
+    (tbsim/models/trace_helpers.py:231-268) on the same weights and features: same ATen ops, 1e-5 of the scale
+    (the reference applies BatchNorm as a module, here it is a folded affine)."""
+    from trace_amd.map_encoder import MapEncoder
+    sd, feats, want = _decoder_fixture()
+    got = MapEncoder(sd, device="cpu", backend="torch").decode(feats)
+    assert got.shape == want.shape
+    err = float((got - want).abs().max())
+    assert err <= 1e-5 * float(want.abs().max()), err

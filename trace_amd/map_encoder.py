@@ -16,8 +16,11 @@ max-pool, bilinear up-sampling and LayerNorm kernels) through the C ABI (include
 SURVEY.md section 8(f)-2).  Backend "torch" is the same network as PyTorch-ROCm ops (MIOpen
 convolutions): the comparison path of the tests, and the path for other raster sizes and the CPU.
 
-PARITY UNPINNED: torchvision is absent from the build container, so the reference's encoder
-cannot be instantiated to emit golden vectors; the tests check this module
+PARITY: the decoder half (MapGridDecoder + Up / DoubleConv / ConvBlock + LayerNorm) is pinned against the
+reference's own classes, which are pure torch and import through oracle/ref_harness.py
+(oracle/gen_golden_map_decoder.py -> tests/golden/map_decoder.npz; `MapEncoder.decode`).  The ResNet-18 TRUNK
+is torchvision's; torchvision is absent from the build container, so the reference's trunk cannot be
+instantiated to emit golden vectors and that half stays unpinned -- the tests check it
 against an independent nn.Module assembly of the same layers, CPU vs GPU.
 The state_dict keys are the reference's (`map_encoder.encoder_heads.map_model.*`,
 `map_encoder.decoder.*`); the `encoder_heads.` level comes from torch.fx's feature extractor.
@@ -232,7 +235,11 @@ class MapEncoder:
             for bi in range(2):
                 x = self._basic_block(x, "%slayer%d.%d." % (_TRUNK, li, bi), 2 if (bi == 0 and li > 1) else 1)
             feats.append(x)
-        # MapGridDecoder.forward, trace_helpers.py:259-268
+        return None, self._decode(feats)
+
+    def _decode(self, feats):
+        """MapGridDecoder.forward, trace_helpers.py:259-268, on the trunk's layer1..layer4 features."""
+        p = self.p
         x = F.relu(F.conv2d(feats[3], p[_DEC + "conv1.0.weight"], None, 1, 1))
         x = self._up(x, feats[2], "up1")
         x = self._up(x, feats[1], "up2")
@@ -245,8 +252,21 @@ class MapEncoder:
         x = F.relu(out)
         x = F.conv2d(x, p[_DEC + "conv3.weight"], p[_DEC + "conv3.bias"])
         w, b = p[_DEC + "out_norm.weight"], p[_DEC + "out_norm.bias"]
-        x = F.layer_norm(x.contiguous(), tuple(w.shape), w, b, _LN_EPS)
-        return None, x
+        return F.layer_norm(x.contiguous(), tuple(w.shape), w, b, _LN_EPS)
+
+    @torch.no_grad()
+    def decode(self, feats):
+        """The decoder half alone: ResNet-18 layer1..layer4 features ((B,64,56,56), (B,128,28,28), (B,256,14,14),
+        (B,512,7,7)) -> map_grid_feat (B, grid_dim, 56, 56), i.e. the reference's
+        `MapEncoder.forward(None, encoder_feats=...)` / `MapGridDecoder.forward` (trace_helpers.py:219-229,259-268).
+        This half is pinned against the reference's own classes (tests/golden/map_decoder.npz); the trunk above it
+        is torchvision's and stays unpinned."""
+        feats = [f.to(device=self.device, dtype=torch.float32) for f in feats]
+        assert len(feats) == 4 and [f.shape[1] for f in feats] == [64, 128, 256, 512], [f.shape for f in feats]
+        if self.backend == "hip" and tuple(feats[0].shape[2:]) == (56, 56):
+            return self._decode_hip(feats)
+        self.p = self._p_nchw
+        return self._decode(feats)
 
     # ------------------------------------------------------------------ HIP backend
     def _prepare_hip(self):
@@ -360,24 +380,48 @@ class MapEncoder:
                     cv(h[q1 + "conv1"], (b[tc], 0), (b[t], 0))
                     cv(h[q1 + "conv2"], (b[t], 0), (b[dst[0]], dst[1]), res=(b[tc], 0))
                     x = (b[dst[0]], dst[1])
-                # MapGridDecoder.forward, trace_helpers.py:259-268
-                cv(h["dec1"], (b["d7"], 0), (b["a7"], 0))
-                src = b["a7"]
-                for name, cat, skip_c, mid, o in (("up1", "cat1", 256, "m14", "u1"), ("up2", "cat2", 128, "m28", "u2"),
-                                                  ("up3", "cat3", 64, "m56", "u3")):
-                    _cabi.check(lib.trace_upsample2x(src.data_ptr(), b[cat].data_ptr(), n, src.shape[1], src.shape[2],
-                                                     src.shape[3], b[cat].shape[3], skip_c, st), "trace_upsample2x")
-                    cv(h[name + "a"], (b[cat], 0), (b[mid], 0))
-                    cv(h[name + "b"], (b[mid], 0), (b[o], 0))
-                    src = b[o]
-                # ConvBlock, base_models.py:229-260
-                cv(h["cb1"], (b["u3"], 0), (b["a56"], 0))
-                cv(h["cb2"], (b["a56"], 0), (b["b56"], 0))
-                cv(h["cbs"], (b["u3"], 0), (b["c56"], 0), relu=False)
-                cv(h["cb3"], (b["b56"], 0), (b["a56"], 0), res=(b["c56"], 0))
-                cv(h["out"], (b["a56"], 0), (b["o32"], 0), relu=False)
-                _cabi.check(lib.trace_layernorm_image(b["o32"].data_ptr(), h["ln_w"].data_ptr(), h["ln_b"].data_ptr(),
-                                                      out[i0:].data_ptr(), n, 56 * 56 * gd, _LN_EPS, st),
-                            "trace_layernorm_image")
+                self._decode_hip_chunk(n, b, out[i0:], st)
         # (B, C, H, W) logical shape of the reference on channels-last memory: the sampler's grid layout
+        return out.permute(0, 3, 1, 2)
+
+    def _decode_hip_chunk(self, n, b, out, st):
+        """MapGridDecoder.forward (trace_helpers.py:259-268) on the features the trunk left in the skip windows of
+        the concatenation buffers (cat3 / cat2 / cat1, channel 0 ..) and in d7."""
+        h, lib = self._hip, _cabi.lib()
+        gd = self._p_nchw[_DEC + "conv3.weight"].shape[0]
+        cv = lambda *a, **k: self._conv(n, *a, **k)
+        cv(h["dec1"], (b["d7"], 0), (b["a7"], 0))
+        src = b["a7"]
+        for name, cat, skip_c, mid, o in (("up1", "cat1", 256, "m14", "u1"), ("up2", "cat2", 128, "m28", "u2"),
+                                          ("up3", "cat3", 64, "m56", "u3")):
+            _cabi.check(lib.trace_upsample2x(src.data_ptr(), b[cat].data_ptr(), n, src.shape[1], src.shape[2],
+                                             src.shape[3], b[cat].shape[3], skip_c, st), "trace_upsample2x")
+            cv(h[name + "a"], (b[cat], 0), (b[mid], 0))
+            cv(h[name + "b"], (b[mid], 0), (b[o], 0))
+            src = b[o]
+        # ConvBlock, base_models.py:229-260
+        cv(h["cb1"], (b["u3"], 0), (b["a56"], 0))
+        cv(h["cb2"], (b["a56"], 0), (b["b56"], 0))
+        cv(h["cbs"], (b["u3"], 0), (b["c56"], 0), relu=False)
+        cv(h["cb3"], (b["b56"], 0), (b["a56"], 0), res=(b["c56"], 0))
+        cv(h["out"], (b["a56"], 0), (b["o32"], 0), relu=False)
+        _cabi.check(lib.trace_layernorm_image(b["o32"].data_ptr(), h["ln_w"].data_ptr(), h["ln_b"].data_ptr(),
+                                              out.data_ptr(), n, 56 * 56 * gd, _LN_EPS, st),
+                    "trace_layernorm_image")
+
+    def _decode_hip(self, feats):
+        if self._hip is None:
+            self._prepare_hip()
+        B = feats[0].shape[0]
+        gd = self._p_nchw[_DEC + "conv3.weight"].shape[0]
+        out = torch.empty(B, 56, 56, gd, device=self.device, dtype=torch.float32)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            for i0 in range(0, B, self.HIP_CHUNK):
+                n = min(self.HIP_CHUNK, B - i0)
+                b = self._buffers(min(self.HIP_CHUNK, B))
+                # NCHW features -> the NHWC skip windows the trunk would have written
+                for f, (name, c) in zip(feats, (("cat3", 64), ("cat2", 128), ("cat1", 256), ("d7", 512))):
+                    b[name][:n, :, :, :c] = f[i0:i0 + n].permute(0, 2, 3, 1)
+                self._decode_hip_chunk(n, b, out[i0:], st)
         return out.permute(0, 3, 1, 2)
