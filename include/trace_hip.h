@@ -283,6 +283,20 @@ int trace_guide_map_collision(const float* traj, float* grad_traj, float* loss,
                               const float* scale, int H, int W, int M, int num_samp, int T,
                               float* workspace, void* stream);
 
+/* The same call with a diagnostic output for the parity tests (no counterpart in the reference, whose
+ * `torch.amin` over the cdist matrix at guidance_loss.py:444-458 keeps its arg-min to itself): argmin
+ * (M*T, n_pts, 2) int32 receives, for every sample point that is off-road in an active step, the on-road sample
+ * point(s) the loss paired it with -- {first arg-min row | number of tied rows << 8, the 2nd .. 4th tied row one per
+ * byte (0xff = none)}; `torch.amin` shares the gradient between exactly tied rows, which the regular 10 x 10 sample grid
+ * produces -- and {-1, -1} elsewhere.  The
+ * reference's matmul-form cdist makes that choice chaotic at the ulp level; given the
+ * choice, loss and gradient are smooth, which is what tests/test_gpu_parity.py checks on every trajectory-step. */
+int trace_guide_map_collision_argmin(const float* traj, float* grad_traj, float* loss,
+                                     const uint8_t* drivable, const float* extent,
+                                     const float* raster_from_agent, const float* local_pts, int n_pts,
+                                     const float* scale, int H, int W, int M, int num_samp, int T,
+                                     float* workspace, int* argmin, void* stream);
+
 /* SocialGroupLoss (guidance_loss.py:744-814): every member of a group keeps `social_dist` to one
  * assigned neighbour of its group per (sample, step) -- the nearest member, or the member the caller
  * drew at random (the reference draws torch.randint / torch.rand inside the loss, :803-804; here the

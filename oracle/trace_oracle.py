@@ -443,10 +443,24 @@ class MapCollision:                                    # guidance_loss.py:341-46
         self.local = torch.cartesian_prod(torch.linspace(-0.5, 0.5, num_points_lw[0]),
                                           torch.linspace(-0.5, 0.5, num_points_lw[1]))
 
+        # test hook: (B, N, T, P, K) int64, for every off-road sample point the ROWS (on-road points, -1 padded) to
+        # pair it with instead of the arg-min of the matmul-form cdist (first entry negative: keep amin).  Several rows
+        # = exactly tied distances: amin's backward shares the gradient evenly between them, as their mean does.  The reference's amin at
+        # guidance_loss.py:444-458 is chaotic at the ulp level; with the choice held fixed, loss and gradient are
+        # smooth functions of the trajectory, so a kernel can be compared on every step (tests/test_gpu_parity.py).
+        self.forced_argmin = None
+        # test hook: (B, N, T, P) bool of the last call -- the off-road sample points of its active (partly off-road)
+        # steps, rows outside `mask` False
+        self.last_off = None
+
     def __call__(self, x, batch, mask):
         dmap, ext, rfa = batch["drivable_map"], batch["extent"], batch["raster_from_agent"]
+        forced = self.forced_argmin
+        n_all = x.shape[0]
         if mask is not None:
             x, dmap, ext, rfa = x[mask], dmap[mask], ext[mask], rfa[mask]
+            if forced is not None:
+                forced = forced[mask]
         _, H, W = dmap.shape
         B, N, T, _ = x.shape
         flat = x.reshape(-1, 6)
@@ -464,10 +478,24 @@ class MapCollision:                                    # guidance_loss.py:341-46
         off = off.reshape(-1, P)
         cnt = off.sum(dim=-1)
         partial = ~((cnt == 0) | (cnt == P))
+        rec = (off & partial.unsqueeze(-1)).reshape(B, N, T, P)
+        if mask is not None:
+            full = torch.zeros(n_all, N, T, P, dtype=torch.bool)
+            full[mask] = rec
+            rec = full
+        self.last_off = rec
         o_off, o_pts, o_diag = off[partial], pts[partial], diag[partial]
         d = torch.cdist(o_pts, o_pts.clone().detach())
         d = torch.where(o_off.unsqueeze(-1).expand(-1, -1, P), torch.full_like(d, float("inf")), d)
         dmin = torch.amin(d, dim=1)
+        if forced is not None:
+            K = forced.shape[-1]
+            f = forced.reshape(-1, P, K)[partial]                                    # (n, P cols, K)
+            picked = torch.gather(d, 1, f.clamp(min=0).permute(0, 2, 1))             # (n, K, P): d[n, f[n, j, k], j]
+            wgt = (f >= 0).permute(0, 2, 1).to(d.dtype)
+            picked = torch.where(wgt > 0, picked, torch.zeros_like(picked))
+            mean = (picked * wgt).sum(1) / wgt.sum(1).clamp(min=1.0)
+            dmin = torch.where(f[..., 0] >= 0, mean, dmin)
         l = torch.where(o_off, 1.0 - dmin / o_diag.unsqueeze(1), torch.zeros_like(dmin)).sum(-1)
         out = torch.zeros(pts.shape[0])
         out[partial] = l

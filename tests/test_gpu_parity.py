@@ -147,6 +147,12 @@ def test_denoiser_forward_and_input_vjp(env, w):
         assert err < 2e-4, (t, err)
 
 
+# observed shares / errors of the map-collision stability mask, asserted with a margin (set after the first GPU run
+# of round 3 printed them; round 2 had the loose 0.3 / 2e-3)
+MAPC_STABLE_MIN = 0.75     # observed 0.878
+MAPC_STABLE_ERR = 1e-4     # observed 5.8e-6 (oracle) / 1.9e-6 (golden)
+
+
 def test_guidance_objectives_value_and_grad(env):
     cfg, aps, batch = env["cfg"], env["aps"], env["batch"]
     from trace_amd.guidance import DiffuserGuidance
@@ -174,7 +180,42 @@ def test_guidance_objectives_value_and_grad(env):
         got = gt.cpu().reshape(B, N, T, 6)
         gold = torch.tensor(comp["loss/%s/grad" % lname])
         if lname == "map_collision":
-            # compare the cells (agent, sample, step) where the oracle agrees with itself under
+            # (i) EVERY cell, with the arg-min choice taken out of the comparison: the kernel reports which on-road
+            # point it paired each off-road point with (trace_guide_map_collision_argmin), the oracle's amin is
+            # replaced by that choice (guidance_loss.py:431-458 with a forced arg-min), and loss + gradient must
+            # then agree at 1e-4 on all (agent, sample, step) cells -- what differs between the two is only WHICH
+            # of two nearly equidistant points won, never the arithmetic given the winner.
+            plan2 = dg.build_plan(batch, N, T, DEV)
+            plan2.debug_map_argmin = True
+            gt2 = torch.zeros(B * N, T, 6, device=DEV)
+            ll2 = plan2.evaluate(td, gt2, None)
+            assert torch.equal(gt2, gt) and all(torch.equal(a, b) for a, b in zip(ll, ll2))
+            (am,) = plan2.map_argmin.values()
+            rows, nt = plan2.decode_map_argmin(am)
+            forced = rows.reshape(B, N, T, -1, 4)
+            ties = (nt.reshape(B, N, T, -1) > 4).any(-1)             # more tied rows than the diagnostic reports
+            for scene in guid.scenes:
+                for _, _, _, fn in scene:
+                    fn.forced_argmin = forced
+            trf = traj0.clone().requires_grad_()
+            tot_f, per_f = guid.loss(trf, batch)
+            gforced, = torch.autograd.grad(tot_f, trf)
+            for scene in guid.scenes:
+                for _, _, _, fn in scene:
+                    fn.forced_argmin = None
+            for k, v in per_f.items():
+                assert _rel(torch.nan_to_num(losses[k].cpu()), torch.nan_to_num(v)) < 1e-4, (lname, k)
+            active_f = gforced.abs().amax(-1) > 0
+            assert int(active_f.sum()) >= 90 and int(ties.sum()) == 0, (int(active_f.sum()), int(ties.sum()))
+            n_tied = int((nt > 1).sum())
+            err_f = float(((got - gforced).abs().amax(-1) * (~ties)).max()) / scale
+            # share of active cells where the kernel's choice differs from the oracle's own amin
+            flipped = ((gforced - gref).abs().amax(-1) / scale > 1e-4) & active_f
+            print("map_collision: %d active cells, %d off-road points with exactly tied nearest points, forced-arg-min "
+                  "gradient error %.2e, kernel's choice differs from the oracle's amin on %d cells"
+                  % (int(active_f.sum()), n_tied, err_f, int(flipped.sum())))
+            assert err_f < 1e-4, err_f
+            # (ii) as before: the cells (agent, sample, step) where the oracle agrees with itself under
             # ~1-ulp perturbations of the input trajectory
             pg = torch.Generator().manual_seed(5)
             stable = torch.ones(B, N, T, dtype=torch.bool)
@@ -185,10 +226,11 @@ def test_guidance_objectives_value_and_grad(env):
                 stable &= ((gp - gref).abs().amax(-1) / scale) < 1e-3
             active = gref.abs().amax(-1) > 0
             frac = float((stable & active).sum()) / max(float(active.sum()), 1.0)
-            assert frac > 0.3, frac
             err = float(((got - gref).abs().amax(-1) * stable).max()) / scale
             err_g = float(((got - gold).abs().amax(-1) * stable).max()) / scale
-            assert err < 2e-3 and err_g < 2e-3, (lname, err, err_g, frac)
+            print("map_collision: stable share %.3f, error on the stable cells %.2e (oracle) %.2e (golden)" % (frac, err, err_g))
+            assert frac > MAPC_STABLE_MIN, frac
+            assert err < MAPC_STABLE_ERR and err_g < MAPC_STABLE_ERR, (lname, err, err_g, frac)
             continue
         err = float((got - gref).abs().max()) / scale
         err_g = float((got - gold).abs().max()) / scale      # golden (reference) values too
@@ -263,6 +305,98 @@ def test_teacher_forced_steps_vs_reference_golden(name):
         assert n_stable >= lo * n_tot, (n_stable, n_tot)
         # a flip the 4 oracle probes all missed can still occur; bound their share
         assert n_out <= frac_out * n_stable, (n_out, n_stable)
+
+
+@pytest.mark.parametrize("name", sorted(CHAOTIC))
+def test_teacher_forced_steps_with_the_arg_min_held_fixed(name):
+    """The map-collision cases on EVERY trajectory-step.  `MapCollisionLoss` (guidance_loss.py:431-458) pairs each
+    off-road sample point with its nearest on-road point through a matmul-form cdist whose 1e-4 .. 1e-3 relative noise
+    makes that arg-min flip under 1-ulp changes of the input -- which is why
+    `test_teacher_forced_steps_vs_reference_golden` can only compare the steps on which the reference reproduces
+    itself.  Here the choice is taken out of the comparison instead of masked: each reverse step runs on the GPU from
+    the reference's x_t and reports the pairs the kernel chose (trace_guide_map_collision_argmin); the CPU oracle --
+    bit-equal to the reference on the goldens -- runs the same step with its amin replaced by those pairs; the two
+    results must agree at the 1e-4 bar of every other case on the trajectories of all 100 steps, with two exactly
+    identified, counted and bounded exceptions (below): pixel-edge reclassification of a sample point (<= 1 % of the
+    trajectory-steps, observed 0.1 %) and pairs whose matmul-form distance is ill-conditioned in the reference's own
+    arithmetic (<= 1 % above 1e-4, none above 5e-4, observed 0.6 % of noisy_all)."""
+    c, s = _run_case(None, name, True)
+    cfg = c["cfg"]
+    gold = dict(np.load(os.path.join(GOLDEN, "sample_%s.npz" % name)))
+    d = torch.tensor(gold["diffusion_steps"])
+    B, N, T = d.shape[:3]
+    dsc = orc.scale_traj(cfg, d.reshape(B * N, -1, 6)).reshape(B * N, T, 101, 6)
+    o = orc.OracleSampler(cfg, random_state_dict(cfg, c["sd_seed"]))
+    o.set_guidance(c["guidance"])
+    o.guidance.update(global_t=c["step_index"])
+    aux = o.repeat_aux(orc.get_aux_info(o.sd, cfg, c["batch"], c["w"] != 0.0), N)
+    mapc = [fn for scene in o.guidance.scenes for _, _, _, fn in scene if isinstance(fn, orc.MapCollision)]
+    assert mapc
+    s.debug_map_argmin = True
+    worst, n_tie_traj, n_pairs, n_flipped_vs_gold, n_reclass, worst_reclass = 0.0, 0, 0, 0, 0, 0.0
+    over = []
+    try:
+        for k in range(cfg.n_diffusion_steps):
+            t = cfg.n_diffusion_steps - 1 - k
+            out = s.forward(c["batch"], num_samp=N, class_free_guide_w=c["w"], apply_guidance=c["apply"],
+                            guide_clean=c["clean"], x_init=dsc[:, :, k], steps=[t],
+                            noise_steps=c["noise_steps"][k:k + 1])
+            got = out["pred_traj_scaled"].reshape(B * N, T, 6).cpu()
+            (am,) = out["guidance_plan"].map_argmin.values()
+            rows, nt = out["guidance_plan"].decode_map_argmin(am)
+            n_pairs += int((nt > 0).sum())
+            tie_traj = (nt.reshape(B * N, -1) > 4).any(-1)              # more tied rows than the diagnostic reports
+            forced = rows.reshape(B, N, T, -1, 4)
+            for fn in mapc:
+                fn.forced_argmin = forced if t != 0 else None            # t = 0: guidance is evaluated, not applied
+            tt = torch.full((B * N,), t, dtype=torch.long)
+            op, _ = o.p_sample(dsc[:, :, k], tt, c["batch"], aux, N, c["w"], c["noise_steps"][k], c["apply"],
+                               c["clean"], eval_final=False)
+            rel = ((got - op).abs() / (1.0 + op.abs())).amax(dim=(1, 2))
+            # the loss has a second discontinuity that no arg-min fixes: WHICH sample points are off-road comes from a
+            # truncated pixel index (guidance_loss.py:406-410), so a point within an ulp of a pixel edge can be
+            # classified differently from the two sides' (1-ulp different) trajectories.  Such trajectory-steps are
+            # identified exactly -- the kernel's off-road set differs from the oracle's -- counted, and bounded.
+            off_o = torch.zeros_like(mapc[0].last_off)
+            for fn in mapc:
+                off_o |= fn.last_off
+            reclass = ((nt.reshape(B, N, T, -1) > 0) != off_o).any(-1).any(-1).reshape(B * N)
+            if t == 0:
+                reclass[:] = False
+            n_reclass += int(reclass.sum())
+            n_tie_traj += int(tie_traj.sum())
+            relc = rel * (~tie_traj) * (~reclass)
+            worst = max(worst, float(relc.max()))
+            if t != 0 and bool((relc > 1e-4).any()):
+                # how far does the ORACLE itself move, pairs held fixed, when its input moves by an ulp?  (the
+                # matmul-form distance |a|^2 + |b|^2 - 2ab of a pair 0.1 m apart cancels ~3 digits, and it sits in
+                # the gradient's denominator: smooth, but ill-conditioned)
+                pg = torch.Generator().manual_seed(1000 + k)
+                xp = dsc[:, :, k] * (1 + (torch.rand(dsc[:, :, k].shape, generator=pg) - 0.5) * 6e-7)
+                op2, _ = o.p_sample(xp, tt, c["batch"], aux, N, c["w"], c["noise_steps"][k], c["apply"], c["clean"],
+                                    eval_final=False)
+                sens = ((op2 - op).abs() / (1.0 + op.abs())).amax(dim=(1, 2))
+                for m in torch.nonzero(relc > 1e-4)[:, 0].tolist():
+                    over.append((t, m, float(relc[m]), float(sens[m])))
+            worst_reclass = max(worst_reclass, float((rel * reclass).max()))
+            ref = dsc[:, :, k + 1]
+            n_flipped_vs_gold += int((((op - ref).abs() / (1.0 + ref.abs())).amax(dim=(1, 2)) > 1e-4).sum())
+    finally:
+        for fn in mapc:
+            fn.forced_argmin = None
+    print("%s: %d (off-road point, on-road point) pairs over 100 steps, worst trajectory-step with the kernel's pairs "
+          "%.2e, trajectory-steps with more than 4 tied rows %d, trajectory-steps whose off-road point SET differs "
+          "(pixel-edge reclassification) %d (worst %.2e), trajectory-steps on which the kernel's pairs differ from the "
+          "reference's own (golden) choice %d / %d" % (name, n_pairs, worst, n_tie_traj, n_reclass, worst_reclass,
+                                                       n_flipped_vs_gold, 100 * B * N))
+    print("trajectory-steps above 1e-4 (t, trajectory, HIP vs oracle, oracle vs itself 1 ulp away):", over)
+    assert n_pairs > 1000, n_pairs                      # the loss is active
+    assert n_tie_traj == 0, n_tie_traj
+    assert n_reclass <= 0.01 * 100 * B * N, n_reclass   # observed: 1 / 1000 (clean_all), 0 (noisy_all)
+    # observed: clean_all 0 trajectory-steps above 1e-4 (worst 3.6e-5); noisy_all 6 / 1000 between 1.1e-4 and 2.7e-4,
+    # on which the oracle with the SAME pairs moves by 2e-5 .. 3.5e-4 when its input moves by an ulp (printed above)
+    assert len(over) <= 0.01 * 100 * B * N, over
+    assert worst < 5e-4, worst
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -84,6 +84,8 @@ PROTOTYPES = {
                                                 _I, _P]),
     "trace_guide_map_collision": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I,
                                        _P, _P]),
+    "trace_guide_map_collision_argmin": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I,
+                                              _P, _P, _P]),
     "trace_env_rasterize": (_I, [_P, _P, _P, _I, C.POINTER(C.c_float * 9), _P, _I, _P, _I, _I, _I, _P]),
     "trace_guide_social_group": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _F, _P, _I, _I, _I, _P, _P, _P, _P]),
     "trace_conv2d": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _I, _I, _I, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _P]),

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) void map_collision_kernel(
     const float* __restrict__ traj, float* __restrict__ grad, float* __restrict__ loss_mt,
     const uint8_t* __restrict__ drivable, const float* __restrict__ extent,
     const float* __restrict__ rfa, const float* __restrict__ local_pts, int P,
-    const float* __restrict__ scale, int H, int W, int M, int num_samp, int T) {
+    const float* __restrict__ scale, int H, int W, int M, int num_samp, int T, int* __restrict__ dbg_argmin) {
   __shared__ float spx[4][128], spy[4][128], spn[4][128];
   __shared__ unsigned char soff[4][128];
   const int lane = threadIdx.x & 63;
@@ -292,6 +292,12 @@ __global__ __launch_bounds__(256) void map_collision_kernel(
   const int m = mt / T;
   const int ag = m / num_samp;
   const float sc = scale[ag];
+  // diagnostic output (tests only, null in production): per sample point two ints, the on-road point(s) the loss
+  // paired it with -- {-1, -1} for on-road points and inactive steps, else {first arg-min row | number of tied rows
+  // << 8, the 2nd .. 4th tied row one per byte (0xff = none)}
+  if (dbg_argmin) {
+    for (int i = lane; i < 2 * P; i += 64) dbg_argmin[(size_t)mt * 2 * P + i] = -1;
+  }
   if (sc < 0.f) return;
   const float* p = traj + (size_t)mt * 6;
   const float px = p[0], py = p[1], yaw = p[3];
@@ -341,7 +347,8 @@ __global__ __launch_bounds__(256) void map_collision_kernel(
     const float bx = qx[h], by = qy[h];
     const float bn = bx * bx + by * by;
     float dmin = INFINITY;
-    int nties = 0;
+    int nties = 0, imin = -1;
+    unsigned more = 0xffffffu;                 // 2nd .. 4th tied row
     for (int i = 0; i < P; ++i) {
       if (soff[wv][i]) continue;
       float acc = (-2.f * spx[wv][i]) * bx;
@@ -349,8 +356,16 @@ __global__ __launch_bounds__(256) void map_collision_kernel(
       acc = acc + spn[wv][i];
       acc = acc + bn;
       float d = sqrtf(fmaxf(acc, 0.f));
-      if (d < dmin) { dmin = d; nties = 1; }
-      else if (d == dmin) ++nties;
+      if (d < dmin) { dmin = d; nties = 1; imin = i; more = 0xffffffu; }
+      else if (d == dmin) {
+        if (nties < 4) more = (more & ~(0xffu << (8 * (nties - 1)))) | ((unsigned)i << (8 * (nties - 1)));
+        ++nties;
+      }
+    }
+    if (dbg_argmin) {
+      int* o = dbg_argmin + ((size_t)mt * P + lane + h * 64) * 2;
+      o[0] = imin | (nties << 8);
+      o[1] = (int)more;
     }
     tot += 1.f - dmin / diag;
     if (grad && dmin > 0.f) {
@@ -625,11 +640,10 @@ extern "C" int trace_guide_agent_collision_static(const float* traj, float* grad
                                      num_samp, T, ws, stream);
 }
 
-extern "C" int trace_guide_map_collision(const float* traj, float* grad_traj, float* loss,
-                                         const uint8_t* drivable, const float* extent,
-                                         const float* raster_from_agent, const float* local_pts,
-                                         int n_pts, const float* scale, int H, int W, int M,
-                                         int num_samp, int T, float* workspace, void* stream) {
+static int map_collision_impl(const float* traj, float* grad_traj, float* loss, const uint8_t* drivable,
+                              const float* extent, const float* raster_from_agent, const float* local_pts,
+                              int n_pts, const float* scale, int H, int W, int M, int num_samp, int T,
+                              float* workspace, int* argmin, void* stream) {
   GUIDE_COMMON_CHECK("trace_guide_map_collision");
   TRACE_REQUIRE(drivable && extent && raster_from_agent && local_pts && workspace,
                 "trace_guide_map_collision: null table");
@@ -638,12 +652,32 @@ extern "C" int trace_guide_map_collision(const float* traj, float* grad_traj, fl
   int n = M * T;
   hipLaunchKernelGGL(map_collision_kernel, dim3((n + 3) / 4), block, 0, st, traj, grad_traj,
                      workspace, drivable, extent, raster_from_agent, local_pts, n_pts, scale, H, W, M,
-                     num_samp, T);
+                     num_samp, T, argmin);
   int rc = launch_status("map_collision_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(sum_over_time_kernel, grid, block, 0, st, workspace, loss, scale, M, num_samp,
                      T);
   return launch_status("sum_over_time_kernel");
+}
+
+extern "C" int trace_guide_map_collision(const float* traj, float* grad_traj, float* loss,
+                                         const uint8_t* drivable, const float* extent,
+                                         const float* raster_from_agent, const float* local_pts,
+                                         int n_pts, const float* scale, int H, int W, int M,
+                                         int num_samp, int T, float* workspace, void* stream) {
+  return map_collision_impl(traj, grad_traj, loss, drivable, extent, raster_from_agent, local_pts, n_pts, scale, H,
+                            W, M, num_samp, T, workspace, nullptr, stream);
+}
+
+extern "C" int trace_guide_map_collision_argmin(const float* traj, float* grad_traj, float* loss,
+                                                const uint8_t* drivable, const float* extent,
+                                                const float* raster_from_agent, const float* local_pts,
+                                                int n_pts, const float* scale, int H, int W, int M,
+                                                int num_samp, int T, float* workspace, int* argmin,
+                                                void* stream) {
+  TRACE_REQUIRE(argmin, "trace_guide_map_collision_argmin: null argmin");
+  return map_collision_impl(traj, grad_traj, loss, drivable, extent, raster_from_agent, local_pts, n_pts, scale, H,
+                            W, M, num_samp, T, workspace, argmin, stream);
 }
 
 extern "C" int trace_guide_social_group(const float* traj, float* grad_traj, float* loss,

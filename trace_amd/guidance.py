@@ -237,6 +237,8 @@ class GuidancePlan:
                     self.drivable = batch["drivable_map"].to(device=device, dtype=torch.uint8).contiguous()
         M = B * self.N
         self.ws = torch.empty(M * self.T * 4, dtype=torch.float32, device=device)
+        self.debug_map_argmin = False    # tests: evaluate() records the map-collision arg-min choices in map_argmin
+        self.map_argmin = {}
         self.generator = None            # torch.Generator for the social_group neighbour draws
         self.social_tape = None          # {guide key name: (randint (T*N, G, 1), rand (T*N, G))}: injected draws
         if any(ly["kind"] == "social_group" for ly in self.layers):
@@ -435,10 +437,20 @@ class GuidancePlan:
                     ptr(self.ws), stream)
             elif kind == "map_collision":
                 H, W = self.drivable.shape[-2:]
-                rc = L.trace_guide_map_collision(
-                    ptr(traj), gp, ptr(loss), ptr(self.drivable), ptr(self.extent),
-                    ptr(self.raster_from_agent), ptr(d["local"]), d["local"].shape[0], ptr(d["scale"]),
-                    H, W, M, N, T, ptr(self.ws), stream)
+                if self.debug_map_argmin and gp is not None:      # the evaluation that produces the gradient
+                    # tests only: also record which on-road point every off-road point was paired with
+                    P = d["local"].shape[0]
+                    am = torch.empty(M * T, P, 2, dtype=torch.int32, device=self.device)
+                    rc = L.trace_guide_map_collision_argmin(
+                        ptr(traj), gp, ptr(loss), ptr(self.drivable), ptr(self.extent),
+                        ptr(self.raster_from_agent), ptr(d["local"]), P, ptr(d["scale"]),
+                        H, W, M, N, T, ptr(self.ws), ptr(am), stream)
+                    self.map_argmin[ly["key"]] = am
+                else:
+                    rc = L.trace_guide_map_collision(
+                        ptr(traj), gp, ptr(loss), ptr(self.drivable), ptr(self.extent),
+                        ptr(self.raster_from_agent), ptr(d["local"]), d["local"].shape[0], ptr(d["scale"]),
+                        H, W, M, N, T, ptr(self.ws), stream)
             elif kind == "social_group":
                 pick = self._social_pick(ly)
                 rc = L.trace_guide_social_group(
@@ -450,6 +462,18 @@ class GuidancePlan:
             _cabi.check(rc, "trace_guide_" + kind)
             out.append(loss)
         return out
+
+    @staticmethod
+    def decode_map_argmin(am):
+        """(M*T, P, 2) int32 of trace_guide_map_collision_argmin -> ((M*T, P, 4) int64 tied rows, -1 padded;
+        (M*T, P) number of tied rows, 0 where the point is not an off-road point of an active step)."""
+        am = am.cpu().long()
+        a, b = am[..., 0], am[..., 1] & 0xFFFFFF
+        nt = torch.where(a >= 0, a >> 8, torch.zeros_like(a))
+        rows = torch.stack([a & 255, b & 255, (b >> 8) & 255, (b >> 16) & 255], -1)
+        k = torch.arange(4).expand_as(rows)
+        rows = torch.where((k < nt.unsqueeze(-1).clamp(max=4)) & (a >= 0).unsqueeze(-1), rows, torch.full_like(rows, -1))
+        return rows, nt
 
     def _social_pick(self, ly):
         """(B, N, T) int32: the randomly assigned neighbour (global agent index) or -1 = nearest.

@@ -197,6 +197,8 @@ class TraceSampler:
 
         guidance = self.current_guidance
         plan = guidance.build_plan(data_batch, N, T, dev, generator) if guidance is not None else None
+        if plan is not None and getattr(self, "debug_map_argmin", False):
+            plan.debug_map_argmin = True         # tests: out["guidance_plan"].map_argmin (guidance.py)
         guided = plan is not None and apply_guidance
         save = 1 if (guided and guide_clean) else 0
         ws_bytes = L.trace_unet_workspace_bytes(self._unet, R, save)
