@@ -143,11 +143,12 @@ def launch_ranks(n):
 
 def conv_roofline(model, batch, N, wl, gen, device, n_prof_steps=5):
     """Roofline block of the dominant kernel (conv_bf3_kernel: denoiser forward + input-VJP).
-    Two passes over the same n_prof_steps DDPM steps on the launch stream: pass A is bracketed by ONE pair of
-    HIP events (the undisturbed time of the steps); pass B brackets every conv launch with its own pair
-    (trace_profile_begin/end) and the whole pass with another.  Per-launch events stretch the pass by a few
-    per cent (two extra packets per launch), so the conv time reported is the conv SHARE of pass B applied to
-    the undisturbed time of pass A -- it cannot exceed the step it is part of."""
+    `achieved` and `frac` come from ONE schedule: a pass over n_prof_steps DDPM steps in which every conv launch is
+    bracketed by its own pair of HIP events on the launch stream (trace_profile_begin/end; the denoiser then runs on
+    that one stream -- the two-stream row split of the product path is off while launches are being timed), so
+    conv time = the sum of the launches' own durations, the quantity `rocprofv3 --kernel-trace --stats` reports
+    (profiles/).  The undisturbed two-stream time of the same steps is reported beside it (`ddpm_step_ms`); it is not
+    used in `achieved` / `frac`."""
     from trace_amd import _cabi
     L = _cabi.lib()
     kw = dict(class_free_guide_w=wl["w"], guide_clean=wl["clean"], n_steps=n_prof_steps, generator=gen,
@@ -167,14 +168,12 @@ def conv_roofline(model, batch, N, wl, gen, device, n_prof_steps=5):
     _cabi.check(L.trace_profile_end(C.byref(ms), C.byref(nl), C.byref(fl)), "trace_profile_end")
     torch.cuda.synchronize(device)
     t_a, t_b = ev[0].elapsed_time(ev[1]), ev[2].elapsed_time(ev[3])
-    share = min(ms.value / t_b, 1.0) if t_b > 0 else 0.0
-    conv_ms = share * t_a                               # conv time of the undisturbed pass
+    conv_ms = ms.value                                  # sum of the conv launches' own durations (one stream)
     achieved = fl.value / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    # The conv kernels compute fp32 results on the 16-bit matrix pipe from exactly split operands (DESIGN.md
-    # section 5.1): a launch on the fp16-pair scheme issues 3 MFMA multiply-adds per algorithmic one, a launch on the
-    # bf16-triple scheme 6, the four stride-2 launches still run the fp32 MFMA.  The library adds up each launch's
-    # matrix-pipe time at the dense peak (trace_profile_pipe_seconds); frac = that time / the measured conv time,
-    # and `peak` is the rate this mix of launches would reach with the pipe always busy (achieved / frac).
+    # The conv kernels give fp32 results on the 16-bit matrix pipe: a launch on the fp16-pair
+    # scheme issues 3 MFMA multiply-adds per algorithmic one, a launch on the bf16-triple scheme 6.  The library adds
+    # up each launch's matrix-pipe time at the dense peak (trace_profile_pipe_seconds); frac = that time / the measured
+    # conv time, and `peak` is the rate this mix of launches would reach with the pipe always busy (achieved / frac).
     pipe_ms = float(L.trace_profile_pipe_seconds()) * 1e3
     frac = pipe_ms / conv_ms if conv_ms > 0 else 0.0
     peak = achieved / frac if frac > 0 else 0.0
@@ -189,21 +188,24 @@ def conv_roofline(model, batch, N, wl, gen, device, n_prof_steps=5):
             traffic = float(json.load(f)["hbm_bytes_per_launch"])
     scheme = "fp16x2" if int(L.trace_conv_scheme(-1)) else "bf16x3"
     return {"bound": "mfma",
-            "kernel": "conv_bf3_kernel (fp32 implicit-GEMM conv from exactly split operands, fp32 accumulate; "
-                      "scheme %s: %s MFMA terms per product)" % (scheme, "3 fp16" if scheme == "fp16x2" else "6 bf16"),
+            "kernel": "conv_bf3_kernel (implicit-GEMM conv, fp32 in / fp32 out, fp32 accumulate; scheme %s: %s)" % (
+                scheme, "each operand as two fp16 terms (>= 22 significand bits) under exact power-of-two block "
+                        "scales, 3 MFMA terms per product" if scheme == "fp16x2" else
+                        "each operand as three bf16 terms (24 significand bits), 6 MFMA terms per product"),
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": frac,
             "peak_is": "algorithmic FLOP/s of this launch mix with the matrix pipe always busy: sum of the launches' "
                        "algorithmic FLOPs / sum of their MFMA FLOPs (x3 fp16-pair, x6 bf16-triple) at the dense "
-                       "16-bit MFMA peak of 2500 TFLOP/s (fp32-MFMA launches at 157.3)",
+                       "16-bit MFMA peak of 2500 TFLOP/s",
             "frac_of_bf16x6_roof": achieved / (mfma16_peak / 6.0),
             "frac_of_fp32_mfma_peak": achieved / fp32_mfma_peak,
             "traffic": traffic, "launches": int(nl.value),
             "avg_launch_us": conv_ms * 1e3 / max(nl.value, 1),
             "conv_ms_per_ddpm_step": conv_ms / n_prof_steps,
             "pipe_ms_at_peak_per_ddpm_step": pipe_ms / n_prof_steps,
+            "stream_mode": "one stream, per-launch HIP events (both numerator and denominator of achieved / frac)",
+            "event_pass_ms_per_ddpm_step": t_b / n_prof_steps,
             "ddpm_step_ms": t_a / n_prof_steps,
-            "conv_share_of_step": share,
-            "per_launch_event_pass": {"sum_conv_ms": ms.value, "pass_ms": t_b}}
+            "ddpm_step_ms_is": "undisturbed product schedule (two row halves on two streams), not used above"}
 
 
 def hbm_kernel_table(model, cfg, N, device, reps=20):
@@ -304,6 +306,14 @@ def main():
                          "launch-bound small batches such as cfg1")
     ap.add_argument("--host-inputs", action="store_true",
                     help="keep the observation batch in host memory (PCIe-inclusive rate; not the headline)")
+    ap.add_argument("--sub-scenes", type=int, default=64,
+                    help="strong scaling: scenes per sampling call of a rank (sub-batch boundaries are global, so a "
+                         "rank count that divides total / sub-scenes leaves every sub-batch intact)")
+    ap.add_argument("--digest", action="store_true",
+                    help="add config.plan_sha1: SHA-1 of the gathered plans of the last step (rank-count invariance)")
+    ap.add_argument("--precomputed-map-grid", action="store_true",
+                    help="pass the map feature grid in the batch instead of the raster image (the map encoder then "
+                         "runs outside the timed call; not the headline)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: every rank owns the workload's scenes; strong: 8x the workload's scenes in "
                          "total (BASELINE configs[3]: 512 scenes), sharded scene-wise over the ranks")
@@ -342,6 +352,7 @@ def main():
     N = wl["samples"]
     gen = torch.Generator(device=device).manual_seed(7 + rank)
     calls_per_step = 1
+    encode_in_call = False
     if wl.get("closed_loop"):
         # the replanning loop: device-resident environment -> observation -> sampler -> step, scenes of
         # this rank only (scene ids offset by rank so every rank simulates different scenes)
@@ -385,6 +396,14 @@ def main():
             obs = env.get_observation()["agents"]
             return (obs["centroid"], stats)
     else:
+        # the metric includes the conditioning.  The batch carries the rasterised map `image`, not a
+        # precomputed feature grid: every call encodes it (ResNet-18 + MapGridDecoder on the library's kernels; with
+        # classifier-free guidance also the filled image of the unconditional pass, trace.py:271-275)
+        encode_in_call = args.scaling == "weak" and not args.precomputed_map_grid
+        if encode_in_call:
+            from trace_amd.map_encoder import random_map_encoder_state_dict
+            sd = dict(sd)
+            sd.update(random_map_encoder_state_dict(cfg.image_shape[0], cfg.map_grid_feature_dim, cfg.image_shape[1:], seed=0))
         model = DiffuserTrafficModel(cfg, sd, device)
         policy = PolicyWrapper.wrap_controller(model, num_action_samples=N, class_free_guide_w=wl["w"],
                                                guide_as_filter_only=bool(wl.get("filter_only")), guide_with_gt=False,
@@ -394,7 +413,7 @@ def main():
             # rank balanced by agent count; a rank walks its range in sub-batches of <= SUB scenes
             from trace_amd.distributed import shard_scenes
             from trace_amd.guidance import DiffuserGuidance
-            SUB = 64
+            SUB = args.sub_scenes
             total_scenes = 8 * wl["scenes"]
             s0, s1 = shard_scenes([wl["agents"]] * total_scenes, world)[rank]
             subs = []
@@ -404,21 +423,28 @@ def main():
                 batch_c.pop("image", None)                         # the map encoder's output is in the batch
                 if not args.host_inputs:
                     batch_c = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in batch_c.items()}
-                subs.append((batch_c, DiffuserGuidance(guid_c, batch_c) if guid_c is not None else None, sum(aps_c)))
+                subs.append((batch_c, DiffuserGuidance(guid_c, batch_c) if guid_c is not None else None, sum(aps_c), c0))
                 print("[bench] rank %d: scenes %d..%d ready" % (rank, c0, c0 + wl_c["scenes"]), file=sys.stderr, flush=True)
-            B = sum(b for _, _, b in subs)
+            B = sum(b for _, _, b, _ in subs)
         else:
             aps, batch, guidance = build_inputs(cfg, wl, 100 + rank, None if args.host_inputs else device)
             B = sum(aps)
             if guidance is not None:
                 model.set_guidance(guidance, batch)
-            subs = [(batch, model.sampler.current_guidance, B)]
+            if encode_in_call:
+                assert "image" in batch and model.sampler.map_encoder is not None
+                batch = {k: v for k, v in batch.items() if k not in ("map_grid_feat", "map_grid_feat_non_cond")}
+            subs = [(batch, model.sampler.current_guidance, B, None)]
         M = B * N
 
         def one_step(i):
             outs = []
-            for batch_c, guid_c, b_c in subs:
+            for batch_c, guid_c, b_c, c0 in subs:
                 model.sampler.current_guidance = guid_c
+                if c0 is not None:
+                    # strong scaling: the noise of a sub-batch is a function of its first GLOBAL scene index and the
+                    # step, not of the rank that happens to own it -- the gathered plans are rank-count invariant
+                    gen.manual_seed(7000 + 131 * c0 + i)
                 action, info = policy.get_action(batch_c, step_index=i, generator=gen, use_graph=args.graph)
                 scores = info.get("guide_scores")
                 if scores is None:
@@ -452,7 +478,15 @@ def main():
     hbm_kernels = None
     if not args.no_roofline and rank == 0 and not wl.get("closed_loop"):
         model.sampler.current_guidance = subs[0][1]
-        roofline = conv_roofline(model, batch, N, wl, gen, device)
+        batch_r = batch
+        if "map_grid_feat" not in batch:
+            # the profiled passes time a few DDPM steps of the denoiser: give them the grids once, so that the map
+            # encoder (once per CALL in the headline) does not sit inside a 5-step pass
+            aux = model.sampler.get_aux_info(batch, wl["w"] != 0.0)
+            batch_r = dict(batch, map_grid_feat=aux["map_grid_feat"])
+            if wl["w"] != 0.0:
+                batch_r["map_grid_feat_non_cond"] = aux["map_grid_feat_non_cond"]
+        roofline = conv_roofline(model, batch_r, N, wl, gen, device)
         hbm_kernels = hbm_kernel_table(model, cfg, N, device)
     if world > 1:
         dist.barrier()
@@ -465,10 +499,12 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 results everywhere; the denoiser GEMMs evaluate each fp32 product from exactly split "
-                          "operands on the 16-bit matrix pipe with fp32 accumulation: two fp16 terms with "
-                          "power-of-two operand scales (3 MFMA terms; rms error vs fp64 3.6e-7 at K=1280, the fp32 "
-                          "MFMA's is 5.8e-7) or three bf16 terms (6 MFMA terms, 5.3e-7) -- DESIGN.md section 5.1",
+            "dtype_note": "fp32 tensors everywhere; the denoiser GEMMs run on the 16-bit matrix pipe with fp32 "
+                          "accumulation, each fp32 operand as two fp16 terms (>= 22 of its 24 significand bits) under "
+                          "exact power-of-two scales (per layer for weights, per 16 trajectories for activations), "
+                          "3 MFMA terms per product, the l*l' term dropped: rms error vs fp64 3.6e-7 at K=1280 where "
+                          "the fp32 MFMA's is 5.8e-7; launches without operand scales use three bf16 terms (all 24 "
+                          "bits, 6 MFMA terms, 5.3e-7) -- DESIGN.md section 5.1.1",
             "data": "synthetic (seeded ORCA-style scenes, random-init orca_mixed weights)"
                     + ("; inputs in HOST memory, PCIe copy inside the timed region" if args.host_inputs else ""),
             "config": {"workload": args.workload, "agents_per_gpu": B, "samples_per_agent": N,
@@ -476,10 +512,18 @@ def main():
                        "horizon": cfg.horizon, "class_free_guide_w": wl["w"],
                        "guidance": wl["guide"], "guide_clean": wl["clean"], "hip_graph": bool(args.graph),
                        "guide_as_filter_only": bool(wl.get("filter_only")),
+                       "map_encoder_in_call": bool(wl.get("closed_loop")) or bool(encode_in_call),
                        "sampling_calls_per_step": calls_per_step,
                        "total_agents": B * world if args.scaling == "weak" else 8 * wl["scenes"] * wl["agents"],
                        "parallelism": "scenes sharded over %d GPU(s), all-gather of scores/plans" % world},
         }
+        if args.digest:
+            import hashlib
+            h = hashlib.sha1()
+            for t in out[:2]:
+                h.update(t.detach().float().cpu().contiguous().numpy().tobytes())
+            res["config"]["plan_sha1"] = h.hexdigest()
+            res["config"]["plan_rows"] = int(out[0].shape[0])
         if roofline is not None:
             res["roofline"] = roofline
             res["hbm_kernels"] = hbm_kernels

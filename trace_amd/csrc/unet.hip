@@ -494,6 +494,9 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
       frexpf(wmax, &e);                // wmax in [2^(e-1), 2^e)
       wexp = 14 - e;
     }
+    // a layer whose largest |weight| lies outside [2^-27, 2^24) would need a clamped exponent (scaled weights beyond
+    // fp16's range or far into its subnormals): such a layer gets no fp16 stream and stays on the bf16-triple kernel
+    const bool wexp_ok = wexp >= -10 && wexp <= 40;
     wexp = wexp < -10 ? -10 : (wexp > 40 ? 40 : wexp);
     std::vector<uint16_t> hh((size_t)(cout / 16) * nsl * 2 * 64 * 8, 0);
     auto f16_bits = [](float v) -> uint16_t {
@@ -524,7 +527,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
     uint16_t* dh = nullptr;
     rc = upload(u, hh, &dh);
     if (rc) return rc;
-    pc->wh = dh;
+    pc->wh = wexp_ok ? dh : nullptr;
     pc->wexp = wexp;
   }
   return TRACE_OK;
