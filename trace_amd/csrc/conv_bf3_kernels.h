@@ -6,9 +6,8 @@
 // the product).  Measured against an fp64 sum at K = 1280 (scripts/probe/bf16x3.hip): rms relative
 // error 5.3e-7, the native fp32 MFMA 5.8e-7; rate 405 vs 154 fp32-equivalent TFLOP/s.
 //
-// Same tile as conv_gemm_kernel (conv_kernels.h): 208 rows x 64 output channels per workgroup, wave w
-// owns channels 16w .. 16w+15 and all 13 row tiles, identical accumulator layout, so the fused
-// epilogues (GroupNorm + Mish forward / backward, residuals) are shared.
+// Tile: 208 rows x 64 output channels per workgroup, wave w owns channels 16w .. 16w+15 and all 13 row tiles;
+// the fused epilogues (GroupNorm + Mish forward / backward, residuals) are conv_kernels.h's conv_epilogue.
 //
 // A operand: activations stay fp32 in HBM.  A chunk of 32 channels is fetched global -> VGPR
 //            (8 channels x 1 position per thread and pass, dword buffer loads coalesced along the
@@ -38,17 +37,14 @@ namespace trace {
 #define TRACE_BF3_NW 4            // waves per workgroup of the full-chip launches (small launches: launch_conv_bf3)
 #endif
 // IS = input stride (2: the down-sampling convs and the transposed convs' dgrad), UP = zero-stuffing factor
-// WIDE: an 8-wave workgroup that owns 128 output channels (wave w = column tile w, all row tiles) instead of 64
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW, int CHN = 32, int IS = 1,
-          bool WIDE = false>
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int NW = TRACE_BF3_NW, int CHN = 32, int IS = 1>
 struct Bf3Geom {
-  static_assert(!WIDE || NW == 8, "wide workgroups have 8 waves");
   static_assert(IS == 1 || (IS == 2 && UP == 1), "stride 2 without zero-stuffing");
   static constexpr int NTH = NW * 64;                      // threads per workgroup
   static_assert(NW == 4 || NW == 8 || NW == 16, "4, 8 or 16 waves per workgroup");
   // wave w owns column tile w & 3 and part w >> 2 of the row tiles: the NRT tiles are dealt to NW / 4 parts,
   // the first NRT % NPART parts take one more
-  static constexpr int NPART = WIDE ? 1 : NW / 4;
+  static constexpr int NPART = NW / 4;
   static_assert(CHN == 32 || CHN == 64, "chunks of 32 or 64 channels");
   static constexpr int CH = CHN;                           // channels per chunk = CH / 32 MFMA k-slices per tap
   static constexpr int NOCT = CH / 8;                      // channel octets = (plane, octet) arrays per plane
@@ -74,8 +70,8 @@ struct Bf3Geom {
   static constexpr int NUT = (NU + NTH - 1) / NTH;
   static constexpr int NACC = (NRT + NPART - 1) / NPART;       // accumulator tiles per wave (the larger parts)
   static constexpr int NREM = NRT % NPART;                     // parts that have NACC tiles (0: all of them)
-  // the output tile (conv_epilogue) + the 32-channel-group exchange area of conv_epilogue_fwd_rows
-  static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float) + 2 * 4 * TB * sizeof(float);
+  // the output tile (conv_epilogue)
+  static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float);
   static constexpr size_t LDS_BYTES = (size_t)NPLMAX * PLANE > EPI_BYTES ? (size_t)NPLMAX * PLANE : EPI_BYTES;
   static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0 && PPT * NRT == L_OUT && PPT * TB == 16, "bad tile");
   static_assert(PLANE + NOCT * SUB < 131072, "plane offsets stay small");
@@ -87,11 +83,7 @@ struct Bf3Geom {
 #ifndef TRACE_BF3_WGS
 #define TRACE_BF3_WGS 2           // resident workgroups per CU the register budget is sized for
 #endif
-#ifndef TRACE_BF3_WGS_PLN
-#define TRACE_BF3_WGS_PLN 2       // ... when the input comes as pre-split planes (no staging registers)
-#endif
-// PLN: the input is staged from pre-split bf16 plane tensors (ConvArgs::inp / in2p) by LDS-DMA loads; otherwise
-// from the fp32 tensor through registers with the split in the kernel.
+// The input is staged from the fp32 tensor through registers, with the split in the kernel.
 // MINW = waves per SIMD the register budget is sized for (2: up to 256 VGPRs)
 // SCH = 0: three bf16 planes, six MFMAs per product (header of this file).
 // SCH = 1: TWO fp16 planes, a s = h + l with s a power of two that brings the operand into fp16's range (the
@@ -102,18 +94,11 @@ struct Bf3Geom {
 //          MFMA 5.8e-7 -- half the fp32 accumulations), at twice the rate.  Same LDS image, tile and epilogue.
 // CHN = channels per chunk (LDS image / barrier pair): 32, or 64 for the fp16 scheme (half the chunk switches; the
 //       two k-slices of a tap are multiplied one after the other, the next chunk's loads issued half in each).
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1, bool WIDE = false,
-          bool FROM_TILE = false, int WPF = TRACE_BF3_WPF>
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int SCH, int NW = TRACE_BF3_NW,
+          int MINW = TRACE_BF3_WGS * NW / 4, int CHN = 32, int IS = 1, int WPF = TRACE_BF3_WPF>
 __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, const int ct) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS, WIDE>;
-  // FROM_TILE: the (single, 64-channel) input chunk is the finished activation a previous conv of the same workgroup
-  // left in the LDS output tile ([trajectory][channel][position] fp32); its scale comes from the tile's own maximum
-  static_assert(!FROM_TILE || (SCH == 1 && CHN == 64 && UP == 1 && IS == 1 && NW == 4 && !WIDE && !PLN),
-                "tile-staged input: fp16 scheme, one 64-channel chunk, stride 1");
-  static_assert(!WIDE || (SCH == 1 && !PLN), "wide workgroups: fp16 scheme");
-  static_assert(IS == 1 || !PLN, "stride 2: register staging only");
-  static_assert(SCH == 0 || (SCH == 1 && !PLN), "two schemes; the plane tensors are bf16 x 3 only");
+  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS>;
+  static_assert(SCH == 0 || SCH == 1, "two operand schemes");
   static_assert(CHN == 32 || SCH == 1, "64-channel chunks: fp16 scheme only");
   constexpr int NH = CHN / 32;                   // k-slices per tap and chunk
   constexpr int NPL = SCH == 1 ? 2 : 3;
@@ -127,14 +112,14 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   const int wave = tid >> 6;
   // wave -> (column tile, row tiles).  A workgroup's waves go to the SIMDs cyclically, so the waves of one
   // column tile (w, w + 4, ...) share a SIMD and every SIMD carries the same MFMA load.
-  const int cwave = WIDE ? wave : (wave & 3);
-  const int rpart = WIDE ? 0 : (wave >> 2);
+  const int cwave = wave & 3;
+  const int rpart = wave >> 2;
   constexpr int NREM = G::NREM;
   const int nrtw = (NREM == 0 || rpart < NREM) ? NACC : NACC - 1;
   const int rt0 = NREM == 0 ? rpart * NACC : (rpart < NREM ? rpart * NACC : NREM * NACC + (rpart - NREM) * (NACC - 1));
   if (rb * TB >= a.rows) return;
   const int traj0 = rb * TB;
-  const int co0 = ct * (WIDE ? 128 : 64);
+  const int co0 = ct * 64;
   TRACE_STAMP(0);
 #ifdef TRACE_CONV_STAMPS
   if (a.dbg && threadIdx.x == 0) {
@@ -146,7 +131,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   // the largest |value| of their group of 16 (both K sources share the accumulators, hence one scale), so the
   // scaled maximum lies in [2^14, 2^15); the accumulators are scaled back by 2^-(14 - E) 2^-wexp
   float ascale = 1.f, oscale = 1.f;
-  if constexpr (SCH == 1 && !FROM_TILE) {
+  if constexpr (SCH == 1) {
     unsigned am = __hip_atomic_load(a.in_amax + (traj0 >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (a.cin2) {
       const unsigned am2 = __hip_atomic_load(a.in2_amax + (traj0 >> 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -166,59 +151,18 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   // ---- staging ------------------------------------------------------------------------------
   const int nch1 = a.cin / CH;
   const int nch = nch1 + a.cin2 / CH;
-  // (a) planes: wave w copies channel octet w of the chunk, three planes x NPIECE pieces of 64 cells (1 KiB,
-  // one LDS-DMA wave-instruction: lane -> consecutive 16-byte LDS cells, per-lane source address).  Cell s of a
-  // (plane, octet) array is position s % LP - PADL of trajectory s / LP; halo, zero-stuffing and padding cells
-  // read the 16 zero bytes of a.zero_cell, so the image needs no separate zero fill.
-  constexpr int SUBC = SUB / 16;
-  constexpr int NPIECE = (SUBC + 63) / 64;
-  int psrc[PLN ? NPIECE : 1];                  // (trajectory << 16 | input position) of the lane's cell, -1 = zeros
-  if constexpr (PLN) {
-#pragma unroll
-    for (int j = 0; j < NPIECE; ++j) {
-      const int sc = 64 * j + lane;
-      const int tr = sc / LP;
-      const int ii = sc - tr * LP - PADL;
-      const bool ok = sc < G::S && ii >= 0 && (ii % UP) == 0 && (ii / UP) < L_IN && traj0 + tr < a.rows;
-      psrc[j] = ok ? (tr << 16) | (ii / UP) : -1;
-    }
-  }
-  auto stage_dma = [&](int ch) {
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-    const bool second = ch >= nch1;
-    const char* base = reinterpret_cast<const char*>(second ? a.in2p : a.inp);
-    const int noct = second ? a.in2p_noct : a.inp_noct;
-    const int oct = (second ? a.in2p_oct0 + (ch - nch1) * 4 : a.inp_oct0 + ch * 4) + cwave;
-    const size_t rowcells = (size_t)3 * noct * L_IN;             // cells per trajectory
-    const char* const zero = reinterpret_cast<const char*>(a.zero_cell);
-    const char* tb = base + ((size_t)traj0 * rowcells + (size_t)oct * L_IN) * 16;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-      for (int j = 0; j < NPIECE; ++j) {
-        const int ps = psrc[j];
-        const char* src = ps >= 0 ? tb + ((size_t)(ps >> 16) * rowcells + (size_t)(ps & 0xffff)) * 16 : zero;
-        char* dst = ldsb + pl * PLANE + cwave * SUB + j * 1024;      // wave-uniform
-        if ((SUBC % 64 == 0) || j + 1 < NPIECE || 64 * j + lane < SUBC)
-          __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
-      }
-      tb += (size_t)noct * L_IN * 16;                               // next plane
-    }
-  };
-
-  // (b) fp32 tensor through registers
+  // the fp32 tensor goes through registers
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
       0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.in2 ? a.in2 : a.in), 0,
       a.in2 ? (unsigned)((size_t)a.rows * a.in2_tstride * sizeof(float)) : 0u, 0x00020000);
-  constexpr int NUTR = PLN ? 1 : NUT;          // register-staging state only exists without planes
+  constexpr int NUTR = NUT;
   // unit q = tid + NTH j: octet o = q / NPOS, position pp = q % NPOS (lanes run along positions)
   unsigned spk[NUTR];           // (trajectory in tile) << 20 | float offset inside the chunk
   unsigned wofs[NUTR];          // LDS byte offset of the unit inside a plane
-  if constexpr (!PLN) {
+  {
 #pragma unroll
     for (int j = 0; j < NUT; ++j) {
       const int q = tid + NTH * j;
@@ -235,7 +179,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   // ch < 0 (no next chunk): the loads are still issued, at an offset outside the descriptor's range (zeros, no
   // memory access) -- a conditional load would make the compiler copy all staging registers at every chunk
   auto stage_load_unit = [&](int ch, int j) {
-    if constexpr (!PLN) {
+    {
       const bool none = ch < 0;
       const bool second = ch >= nch1;
       const int tstride = second ? a.in2_tstride : a.in_tstride;
@@ -256,11 +200,11 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #ifndef TRACE_BF3_SPLIT_IN_K
 #define TRACE_BF3_SPLIT_IN_K 0    // split the next chunk into bf16 planes between the MFMAs of the current one
 #endif
-  constexpr bool SPLITK = TRACE_BF3_SPLIT_IN_K && TAPS > 1 && !PLN;     // the 1x1 kernels have no MFMA shadow to hide it in
+  constexpr bool SPLITK = TRACE_BF3_SPLIT_IN_K && TAPS > 1;     // the 1x1 kernels have no MFMA shadow to hide it in
   constexpr int NUTS = SCH == 1 ? 1 : NUTR;      // the fp16 scheme splits inside stage_write
   u32x4v sph[NUTS], spm[NUTS], spl[NUTS];
   auto split_unit = [&](int j) {
-    if constexpr (SCH == 0 && !PLN) split8_bf16(stg[j], sph[j], spm[j], spl[j]);
+    if constexpr (SCH == 0) split8_bf16(stg[j], sph[j], spm[j], spl[j]);
   };
   // the bf16 planes of the staged chunk go to LDS from sph / spm / spl
   auto stage_write = [&]() {
@@ -275,7 +219,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
           *reinterpret_cast<u32x4v*>(p + PLANE) = l;
         }
       }
-    } else if constexpr (!PLN) {
+    } else {
 #pragma unroll
       for (int j = 0; j < NUT; ++j) {
         if ((NU % NTH == 0) || (tid + NTH * j < NU)) {
@@ -288,35 +232,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
     }
   };
 
-  if constexpr (FROM_TILE) {
-    float m = 0.f;
+  {
 #pragma unroll
-    for (int j = 0; j < NUT; ++j) {
-      const bool live = (NU % NTH == 0) || (tid + NTH * j < NU);
-      const float* src = lds + (live ? (spk[j] >> 20) * (64 * L_OUT) + (spk[j] & 0xfffffu) : 0u);
-#pragma unroll
-      for (int jj = 0; jj < 8; ++jj) {
-        stg[j][jj] = src[jj * L_OUT];
-        m = fmaxf(m, fabsf(stg[j][jj]));
-      }
-    }
-    m = wave_max_nonneg(m);
-    __syncthreads();                           // every thread has its part of the tile in registers
-    if (lane == 0) lds[wave] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(lds[0], lds[1]), fmaxf(lds[2], lds[3]));
-    int ef = (int)(__builtin_bit_cast(unsigned, m) >> 23);
-    ef = ef < 56 ? 56 : (ef > 253 ? 253 : ef);
-    const int sf = 268 - ef;
-    ascale = __builtin_bit_cast(float, (unsigned)sf << 23);
-    oscale = __builtin_bit_cast(float, (unsigned)(254 - sf - a.wexp) << 23);
-    __syncthreads();                           // the scale is read before the image overwrites it
-  }
-  if constexpr (!PLN) {
-    if constexpr (!FROM_TILE) {
-#pragma unroll
-      for (int j = 0; j < NUT; ++j) stage_load_unit(0, j);
-    }
+    for (int j = 0; j < NUT; ++j) stage_load_unit(0, j);
     // halo / zero-stuffing positions are written once; data positions are rewritten by every chunk
     if constexpr (UP == 1 && TAPS == 1 && IS == 1) {
     } else if constexpr (UP == 1) {
@@ -355,7 +273,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 
   // weight stream: [col tile][slice][plane][lane] fragments of 8 bf16
   constexpr int WSL = 64 * NPL;                  // fragments per slice
-  const bf16x8* wp = reinterpret_cast<const bf16x8*>(SCH == 1 ? a.wh : a.wb) + ((size_t)(ct * (WIDE ? 8 : 4) + cwave) * a.nsl) * WSL + lane;
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(SCH == 1 ? a.wh : a.wb) + ((size_t)(ct * 4 + cwave) * a.nsl) * WSL + lane;
 #ifndef TRACE_BF3_NST
 #define TRACE_BF3_NST 4           // A-fragment register stages (prefetch distance + 1)
 #endif
@@ -425,7 +343,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #define TRACE_BF3_LOAD_SPREAD 0   // row tiles between the global loads of two staging units of the next chunk (0: all at once)
 #endif
       if constexpr (TRACE_BF3_LOAD_SPREAD == 0) {
-        if (!PLN && n == 1) {
+        if (n == 1) {
 #pragma unroll
           for (int j = J0; j < J1; ++j) stage_load_unit(next, j);
         }
@@ -481,9 +399,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #ifdef TRACE_STAMP_SWITCH       // diagnostic: stamps 4 / 5 = chunk 1's switch (all waves arrived / new image ready)
     if (ch == 1) TRACE_STAMP(4);
 #endif
-    if constexpr (PLN) {
-      stage_dma(ch);            // the barrier below waits for it (vmcnt(0) ahead of the s_barrier)
-    } else {
+    {
 #ifdef TRACE_EXP_NOSTAGE
       if (ch == 0)
 #endif
@@ -505,7 +421,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #ifdef TRACE_EXP_NOSTAGE
     const int next = -1;
 #else
-    const int next = PLN ? -1 : (ch + 1 < nch ? ch + 1 : (SPLITK ? ch : -1));
+    const int next = ch + 1 < nch ? ch + 1 : (SPLITK ? ch : -1);
 #endif
     using IC0 = std::integral_constant<int, 0>;
     using ICT = std::integral_constant<int, TAPS>;
@@ -537,12 +453,6 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   }
 
   if constexpr (TRACE_BF3_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-#ifndef TRACE_BF3_EPI_REGS
-#define TRACE_BF3_EPI_REGS 0      // forward GroupNorm / Mish on the accumulators (conv_epilogue_fwd_rows)
-#endif
-  if constexpr (TRACE_BF3_EPI_REGS && NW == 4 && !WIDE) {
-    if (!a.gnb && !a.head_pred) { conv_epilogue_fwd_rows<L_OUT, TB>(a, acc, lds, traj0, co0, oscale); return; }
-  }
 #ifdef TRACE_EXP_NOEPI
   if (a.rows >= 0) {        // timing-only build: the accumulators stay live, the epilogue never runs
     if (a.rows == 123456789) {
@@ -554,128 +464,18 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
     return;
   }
 #endif
-  if constexpr (WIDE) {
-    // the two 64-channel halves go through the same output tile one after the other: waves 4 h .. 4 h + 3 drop
-    // their accumulators, all eight waves run the passes
-    conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, 0, wave < 4 ? NACC : 0, oscale);
-    conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0 + 64, 0, wave >= 4 ? NACC : 0, oscale);
-  } else {
-    conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw, oscale);
-  }
+  conv_epilogue<L_OUT, TB, 1, NW, NACC>(a, acc, lds, traj0, co0, rt0, nrtw, oscale);
 }
 
 // workgroup id -> (row block, column tile): the ncol column tiles of one row block get ids of the same residue
-// mod 8, 8 apart (same XCD, same time: see conv_gemm_kernel)
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1,
-          int WPF = TRACE_BF3_WPF>
+// mod 8, 8 apart (same XCD, same time: scripts/probe/wg_map.hip measured id -> XCD id % 8, CU (id / 8) % 32)
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int SCH, int NW = TRACE_BF3_NW,
+          int MINW = TRACE_BF3_WGS * NW / 4, int CHN = 32, int IS = 1, int WPF = TRACE_BF3_WPF>
 __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
   const int ncol = a.cout >> 6;
   const int bid = blockIdx.x;
-  conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS, false, false, WPF>(
+  conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, SCH, NW, MINW, CHN, IS, WPF>(
       a, (bid / (8 * ncol)) * 8 + (bid & 7), (bid >> 3) % ncol);
-}
-
-// 8-wave workgroups of 128 output channels, one per CU (fp16 scheme): the activations of a row block are staged
-// and split by half as many workgroups.
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, int CHN>
-__global__ __launch_bounds__(512, 2) void conv_wide_kernel(ConvArgs a) {
-  const int ncol = a.cout >> 7;
-  const int bid = blockIdx.x;
-  conv_bf3_body<L_OUT, UP, TAPS, PADL, TB, false, 1, 8, 2, CHN, 1, true>(a, (bid / (8 * ncol)) * 8 + (bid & 7),
-                                                                        (bid >> 3) % ncol);
-}
-
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, int CHN>
-int launch_conv_wide(const ConvArgs& a, hipStream_t st) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, 8, CHN, 1, true>;
-  if (a.rows <= 0) return TRACE_OK;
-  auto ok128 = [&](const float* p, int tstride, int coff) {
-    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 && (coff * L_OUT) % 4 == 0 &&
-                            (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
-  };
-  TRACE_REQUIRE(a.wh && a.in_amax && (a.cin2 == 0 || (a.in2 && a.in2_amax && UP == 1 && a.in2_tstride % 4 == 0 &&
-                                                       (size_t)(a.rows + TB) * a.in2_tstride * sizeof(float) < 0xffffffffull)) &&
-                    a.cout % 128 == 0 && a.cin % CHN == 0 && a.cin2 % CHN == 0 && a.nsl == TAPS * a.cin / 32 + a.cin2 / 32 &&
-                    (reinterpret_cast<uintptr_t>(a.in) & 3) == 0 &&
-                    (size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull &&
-                    ok128(a.out, a.out_tstride, a.out_coff) && ok128(a.res, a.res_tstride, a.res_coff) &&
-                    ok128(a.res2, a.res2_tstride, a.res2_coff) && ok128(a.ysave, a.cout * L_OUT, 0) &&
-                    ok128(a.out_raw, a.raw_tstride, a.raw_coff) && (!a.pc || a.pt) && !a.outp && !a.rawp,
-                "conv wide: bad arguments (cin=%d cin2=%d cout=%d nsl=%d)", a.cin, a.cin2, a.cout, a.nsl);
-  TRACE_REQUIRE(!a.gnb || (!a.gn && !a.pc && !a.ysave && a.gb_y && a.gb_stats && a.gb_gamma && a.gb_beta &&
-                           a.gb_cg > 0 && (a.gb_cg & (a.gb_cg - 1)) == 0 && a.gb_cg <= 64 && a.gb_cmax % 64 == 0 &&
-                           a.gb_cmax <= a.gb_c && (reinterpret_cast<uintptr_t>(a.gb_y) & 15) == 0),
-                "conv wide: bad GroupNorm-backward epilogue arguments");
-  TRACE_REQUIRE(!a.gn || (a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64), "conv: group size %d", a.cg);
-  constexpr size_t lds_bytes = (size_t)2 * G::PLANE > G::EPI_BYTES ? (size_t)2 * G::PLANE : G::EPI_BYTES;
-  static_assert(lds_bytes <= 160 * 1024, "conv wide: LDS");
-  static unsigned long long attr_done = 0;
-  if (first_launch_on_device(&attr_done)) {
-    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wide_kernel<L_OUT, UP, TAPS, PADL, TB, CHN>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
-  const int nrb = (a.rows + TB - 1) / TB;
-  dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 128));
-  const bool prof = prof_active();
-  if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_wide_kernel<L_OUT, UP, TAPS, PADL, TB, CHN>), grid, dim3(512), lds_bytes, st, a);
-  if (prof) {
-    const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
-    prof_post(st, fl, fl * 3.0 / PEAK_MFMA16_FLOPS);
-  }
-  return launch_status("conv_wide_kernel");
-}
-
-// The two k5 convs of a residual block whose 64 output channels fit one workgroup tile (the L = 52 levels): conv 1's
-// finished activation (GroupNorm + Mish + condition) stays in the LDS output tile and conv 2 stages its single
-// 64-channel chunk from there -- it is never written to or read from HBM (272 MB per block at 10240 rows).  The
-// saved raw outputs, the statistics and conv 2's residual / output are as in the separate launches; conv 2's operand
-// scale comes from the workgroup's own tile instead of the 16-trajectory group (also an exact power of two).
-template <int L_OUT, int TB>
-__global__ __launch_bounds__(256, 2) void conv_block_fwd_kernel(ConvArgs a, ConvArgs b) {
-  const int bid = blockIdx.x;
-  if (bid * TB >= a.rows) return;
-  conv_bf3_body<L_OUT, 1, 5, 2, TB, false, 1, 4, 2, 64, 1, false, false>(a, bid, 0);
-  conv_bf3_body<L_OUT, 1, 5, 2, TB, false, 1, 4, 2, 64, 1, false, true>(b, bid, 0);
-}
-
-template <int L_OUT, int TB>
-int launch_conv_block_fwd(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
-  using G = Bf3Geom<L_OUT, 1, 5, 2, TB, 4, 64, 1>;
-  if (a.rows <= 0) return TRACE_OK;
-  auto ok128 = [&](const float* p, int tstride, int coff) {
-    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 && (coff * L_OUT) % 4 == 0 &&
-                            (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
-  };
-  TRACE_REQUIRE(a.rows == b.rows && a.cout == 64 && b.cout == 64 && b.cin == 64 && a.cin % 64 == 0 && a.cin2 == 0 &&
-                    b.cin2 == 0 && a.wh && b.wh && a.in_amax && a.nsl == 5 * a.cin / 32 && b.nsl == 10 && a.keep_tile &&
-                    !a.out && a.gn && b.gn && !a.gnb && !b.gnb && !a.res && !a.res2 && !a.head_pred && !b.keep_tile &&
-                    a.wexp >= -10 && a.wexp <= 40 && b.wexp >= -10 && b.wexp <= 40,
-                "conv block: bad geometry (cin=%d/%d cout=%d/%d)", a.cin, b.cin, a.cout, b.cout);
-  TRACE_REQUIRE((reinterpret_cast<uintptr_t>(a.in) & 3) == 0 &&
-                    (size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull &&
-                    ok128(a.ysave, 64 * L_OUT, 0) && ok128(b.ysave, 64 * L_OUT, 0) && ok128(b.out, b.out_tstride, b.out_coff) &&
-                    ok128(b.res, b.res_tstride, b.res_coff) && ok128(b.res2, b.res2_tstride, b.res2_coff) &&
-                    (!a.pc || a.pt) && (!b.pc || b.pt) && a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64 &&
-                    b.cg > 0 && (b.cg & (b.cg - 1)) == 0 && b.cg <= 64,
-                "conv block: tensors must be 16-byte aligned per trajectory tile and below 4 GiB");
-  constexpr size_t lds_bytes = (size_t)2 * G::PLANE > G::EPI_BYTES ? (size_t)2 * G::PLANE : G::EPI_BYTES;
-  static_assert(lds_bytes <= 80 * 1024, "conv block: LDS per workgroup too large for two per CU");
-  static unsigned long long attr_done = 0;
-  if (first_launch_on_device(&attr_done)) {
-    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_block_fwd_kernel<L_OUT, TB>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-  }
-  dim3 grid((a.rows + TB - 1) / TB);
-  const bool prof = prof_active();
-  if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_block_fwd_kernel<L_OUT, TB>), grid, dim3(256), lds_bytes, st, a, b);
-  if (prof) {
-    const double fl = 2.0 * (a.alg_macs_per_pos + b.alg_macs_per_pos) * (double)a.rows * L_OUT;
-    prof_post(st, fl, fl * 3.0 / PEAK_MFMA16_FLOPS);
-  }
-  return launch_status("conv_block_fwd_kernel");
 }
 
 // A residual block's first k5 conv (a) and its 1x1 residual conv (b) read the same input: one launch, the column
@@ -688,8 +488,8 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvArgs a, ConvArgs 
   const int bid = blockIdx.x;
   const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
   const int ct = (bid >> 3) % ncol;
-  if (ct < ncol_a) conv_bf3_body<L_OUT, 1, 5, 2, TB, false, 1, 4, 2, CHN, 1>(a, rb, ct);
-  else conv_bf3_body<L_OUT, 1, 1, 0, TB, false, 1, 4, 2, 32, 1>(b, rb, ct - ncol_a);
+  if (ct < ncol_a) conv_bf3_body<L_OUT, 1, 5, 2, TB, 1, 4, 2, CHN, 1>(a, rb, ct);
+  else conv_bf3_body<L_OUT, 1, 1, 0, TB, 1, 4, 2, 32, 1>(b, rb, ct - ncol_a);
 }
 
 template <int L_OUT, int TB>
@@ -735,20 +535,13 @@ int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
   return launch_status("conv_pair_kernel");
 }
 
-template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool PLN, int SCH = 0, int NW = TRACE_BF3_NW,
-          int MINW = (PLN ? TRACE_BF3_WGS_PLN : TRACE_BF3_WGS) * NW / 4, int CHN = 32, int IS = 1,
-          int WPF = TRACE_BF3_WPF>
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, int SCH = 0, int NW = TRACE_BF3_NW,
+          int MINW = TRACE_BF3_WGS * NW / 4, int CHN = 32, int IS = 1, int WPF = TRACE_BF3_WPF>
 int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, NW, CHN, IS>;
   static_assert(CHN == 32 || NW == 4, "64-channel chunks: 4-wave workgroups");
   ConvArgs a = a_in;
   if (a.rows <= 0) return TRACE_OK;
-  TRACE_REQUIRE(!PLN || (a.inp && a.zero_cell && a.inp_noct > 0 && (a.cin2 == 0 || (a.in2p && a.in2p_noct > 0)) &&
-                         (reinterpret_cast<uintptr_t>(a.inp) & 15) == 0 && TB * G::LP < 65536),
-                "conv(bf16x3, planes): plane tensors of the input(s) missing or misaligned");
-  TRACE_REQUIRE((!a.outp || (a.outp_noct > 0 && (reinterpret_cast<uintptr_t>(a.outp) & 15) == 0)) &&
-                    (!a.rawp || (a.rawp_noct > 0 && (reinterpret_cast<uintptr_t>(a.rawp) & 15) == 0)),
-                "conv(bf16x3): bad output plane tensor");
   TRACE_REQUIRE(SCH == 0 || (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax) && a.wexp >= -10 && a.wexp <= 40),
                 "conv(fp16x2): weight stream, weight exponent or input amax missing");
   TRACE_REQUIRE((SCH == 1 || a.wb) && a.cout % 64 == 0 && a.cin % CHN == 0 && a.cin2 % CHN == 0 &&
@@ -784,13 +577,11 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
                                                                                    : G::EPI_BYTES;
   // two workgroups per CU (the stride-2 bf16-triple fallback, 83 KB, runs one per CU)
   static_assert(LDS_NEED <= (IS == 2 && SCH == 0 ? 100 : 80) * 1024, "conv(bf16x3): LDS per workgroup too large");
-  // TRACE_EXP_ONE_WG=1 (experiment): pad the LDS request so that only ONE workgroup fits a CU
-  static const bool one_wg = getenv("TRACE_EXP_ONE_WG") && atoi(getenv("TRACE_EXP_ONE_WG")) != 0;
-  const size_t lds_bytes = one_wg ? (size_t)100 * 1024 : LDS_NEED;
+  constexpr size_t lds_bytes = LDS_NEED;
   static unsigned long long attr_done = 0;      // one bit per device
   if (first_launch_on_device(&attr_done)) {
     TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS, WPF>),
+        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, SCH, NW, MINW, CHN, IS, WPF>),
         hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
   }
   const int nrb = (a.rows + TB - 1) / TB;
@@ -800,7 +591,7 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
 #endif
   const bool prof = prof_active();
   if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, PLN, SCH, NW, MINW, CHN, IS, WPF>), grid, dim3(G::NTH), lds_bytes, st, a);
+  hipLaunchKernelGGL((conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, SCH, NW, MINW, CHN, IS, WPF>), grid, dim3(G::NTH), lds_bytes, st, a);
   if (prof) {
     const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
     prof_post(st, fl, fl * (SCH == 1 ? 3.0 : 6.0) / PEAK_MFMA16_FLOPS);
@@ -808,73 +599,40 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   return launch_status(SCH == 1 ? "conv_bf3_kernel(fp16x2)" : "conv_bf3_kernel");
 }
 
-// planes staging when the caller has the input's plane tensors (and, for a second K source, that one's too).
-// Small launches -- at most one workgroup per CU, so a layer lasts as long as ONE workgroup (the reference's
-// own CPU-runnable case, 320 trajectories: 80 workgroups) -- run 16 waves per workgroup: each wave then owns a
-// quarter of the row tiles of its column tile (4 / 3 / 3 / 3) and the K loop of the workgroup is a quarter as long.
-#ifndef TRACE_BF3_SMALL_NW
-#define TRACE_BF3_SMALL_NW 16
-#endif
-#ifndef TRACE_CONV_WS_DEFAULT
-#define TRACE_CONV_WS_DEFAULT 0
-#endif
+// Which K loop a launch takes.  Every operand with its scale (weights: wh / wexp, activations: the amax their
+// producer recorded) -> the fp16-pair scheme, 64-channel chunks where the channel counts allow; otherwise the
+// bf16 triple.  trace_conv_ws_mode(1) sends the full-chip multi-tap bf16-triple launches to the persistent
+// wave-specialised kernel (conv_ws_kernels.h; same bits, tests/test_gpu_full_size.py).
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_ws(const ConvArgs& a_in, hipStream_t st);      // conv_ws_kernels.h
 int conv_ws_mode(int mode);                                    // unet.hip (trace_conv_ws_mode)
 int conv_scheme(int mode);                                     // unet.hip (trace_conv_scheme): 0 bf16 x 3, 1 fp16 x 2 where possible
 
-// stride-2 convs (4-wave workgroups, 32-channel chunks: a chunk already stages 2 L_OUT positions per trajectory)
+// stride-2 convs (32-channel chunks: a chunk already stages 2 L_OUT positions per trajectory)
 template <int L_OUT, int TAPS, int PADL, int TB>
 int launch_conv_bf3_s2(const ConvArgs& a, hipStream_t st) {
   constexpr int MW = TRACE_BF3_WGS * TRACE_BF3_NW / 4;
   if (a.wh && a.in_amax)
-    return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, false, 1, TRACE_BF3_NW, MW, 32, 2>(a, st);
-  return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, false, 0, TRACE_BF3_NW, MW, 32, 2>(a, st);
+    return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 32, 2>(a, st);
+  return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, 0, TRACE_BF3_NW, MW, 32, 2>(a, st);
 }
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
-  if (a.inp && (a.cin2 == 0 || a.in2p)) return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, true, 0>(a, st);
+  constexpr int MW = TRACE_BF3_WGS * TRACE_BF3_NW / 4;
   const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
   if (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax)) {          // every operand has its scale: the fp16 pipe
-    // small launches: measured on cfg1 (320 trajectories, 80 workgroups) the 4-wave kernel is the fastest form of
-    // the fp16 scheme (90.6 ms per call; 8 waves 96.4, 16 waves 107.3 -- those instantiations spill), so the
-    // many-wave form is opt-in here (TRACE_F16_SMALL_MAX = largest launch, in workgroups, that takes it)
-    static const int small_max16 = getenv("TRACE_F16_SMALL_MAX") ? atoi(getenv("TRACE_F16_SMALL_MAX")) : 0;
-    if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max16 && (L_OUT < 52 || getenv("TRACE_F16_SMALL_L52")))
-      return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
-#ifndef TRACE_F16_CH
-#define TRACE_F16_CH 64           // channels per chunk of the full-chip fp16 launches with more than one tap (32 / 64)
-#endif
-    // launches of at most one workgroup per CU (cfg1) with two weight slices in flight and 32-channel chunks (the
-    // registers for it): measured slower, 83.6 against 79.9 ms per call -- opt-in (TRACE_F16_LONE_MAX = workgroups)
-    static const int lone_max = getenv("TRACE_F16_LONE_MAX") ? atoi(getenv("TRACE_F16_LONE_MAX")) : 0;
-    if (wgs <= lone_max)
-      return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_NW, TRACE_BF3_WGS * TRACE_BF3_NW / 4, 32, 1, 2>(a, st);
     if constexpr (TAPS > 1) {
-      static const int wide = getenv("TRACE_F16_WIDE") ? atoi(getenv("TRACE_F16_WIDE")) : 0;   // 1: 64-, 2: 32-channel chunks
-      if (wide && a.cout % 128 == 0 && a.cin % 64 == 0 && a.cin2 % 64 == 0 && wgs > 1024) {
-        if (wide == 2) return launch_conv_wide<L_OUT, UP, TAPS, PADL, TB, 32>(a, st);
-        return launch_conv_wide<L_OUT, UP, TAPS, PADL, TB, 64>(a, st);
-      }
-    }
-    if constexpr (TRACE_F16_CH == 64 && TAPS > 1) {
       if (a.cin % 64 == 0 && a.cin2 % 64 == 0)
-        return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1, TRACE_BF3_NW, TRACE_BF3_WGS * TRACE_BF3_NW / 4, 64>(a, st);
+        return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 64>(a, st);
     }
-    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 1>(a, st);
+    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1>(a, st);
   }
-  // bf16-triple small launches: the 16-wave form won 120.7 -> 100.1 ms on cfg1 when every conv was a bf16-triple one;
-  // now only the first block and the conv behind the head are, and the 4-wave form is faster (78.2 against 79.9 ms)
-  static const int small_max = getenv("TRACE_BF3_SMALL_MAX") ? atoi(getenv("TRACE_BF3_SMALL_MAX")) : 0;
-  // full-chip launches of the multi-tap convs: the persistent wave-specialised kernel (conv_ws_kernels.h)
   if constexpr (TAPS > 1) {
-    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > 256 && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.outp && !a.rawp && !a.head_pred)
+    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > 256 && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.head_pred)
       return launch_conv_ws<L_OUT, UP, TAPS, PADL, TB>(a, st);
   }
-  if (TRACE_BF3_SMALL_NW != TRACE_BF3_NW && wgs <= small_max)
-    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 0, TRACE_BF3_SMALL_NW, TRACE_BF3_SMALL_NW / 8>(a, st);
-  return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, false, 0>(a, st);
+  return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 0>(a, st);
 }
 
 }  // namespace trace

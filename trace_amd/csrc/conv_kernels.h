@@ -1,25 +1,16 @@
-// Implicit-GEMM Conv1d kernels on fp32 MFMA (v_mfma_f32_16x16x4_f32) for the TRACE temporal
-// UNet, with the GroupNorm + Mish + (time/cond bias | residual) epilogue fused.
+// Shared pieces of the implicit-GEMM Conv1d kernels of the TRACE temporal UNet (conv_bf3_kernels.h holds the K loop):
+// the launch arguments, the operand splits, and the fused epilogue -- GroupNorm + Mish + (time/cond bias | residual)
+// forward, GroupNorm + Mish backward for the input-VJP.
 //
 // GEMM view of one layer:   out[(traj,l), co] = bias[co] + sum_{tap,ci} in[traj, ci, l*IS + tap] * W[tap,ci,co]
 //   rows   = (trajectory, output position) flattened; a workgroup owns TB whole trajectories
 //            (TB*L_OUT = 208 rows = 13 MFMA row tiles) so GroupNorm statistics never leave it
 //   cols   = 64 output channels per workgroup (4 waves x one 16-wide MFMA column tile)
-//   K      = taps x input channels, streamed in chunks of CH (<=64) channels through LDS
-//
-// A operand: activations staged once per chunk into LDS as [position][channel] (zeroed halo /
-//            zero-stuffing, position stride CH+4 floats), read with one conflict-free ds_read_b128
-//            per (row tile, k-block) that feeds 4 MFMA passes; the reads of the next k-block are
-//            issued during the last pass of the current one
-// B operand: weights pre-packed on the host in MFMA fragment order, streamed L2 -> VGPR with one
-//            coalesced dwordx4 per 16 k (no LDS, no barrier in the K loop), prefetched two
-//            k-blocks ahead so that its wait never covers the (older) staging loads
-// staging  : the next chunk's activations are fetched global -> VGPR (buffer_load b128) before
-//            the K loop of the current chunk and written to LDS after it (issue early / write
-//            late), so HBM / L2 latency hides under the MFMAs
 // epilogue : accumulators -> LDS tile laid out like the global tensor; GroupNorm statistics from
 //            registers (one (trajectory, channel) row per thread, butterfly over the group);
 //            normalise + Mish + cond/time bias + residual(s) and 128-bit stores in one flat pass
+// (Round 1's fp32-MFMA K loop, conv_gemm_kernel, left the tree in round 3: no launch had used it since the stride-2
+// convs moved to conv_bf3_kernel; DESIGN.md section 5.1 keeps its measurements.)
 #pragma once
 #include "common.h"
 
@@ -31,10 +22,7 @@ struct ConvArgs {
   const float* in;     // [rows][in_ctot][L_IN]
   int in_tstride;      // floats per trajectory (multiple of 4)
   int in_coff;         // first input channel (multiple of 16)
-  int cin;             // input channels (multiple of chunk)
-  int chunk;           // channels per LDS stage (selects the template instance)
-  const f32x4* wp;     // packed weights [cout/16][nkb][64]
-  int nkb;             // k-blocks (16 k each) = taps * cin / 16
+  int cin;             // input channels (multiple of 32; channels past the layer's own carry zero weights)
   const float* bias;   // [cout] or null
   float* out;          // [rows][out_ctot][L_OUT]
   int out_tstride;
@@ -82,23 +70,8 @@ struct ConvArgs {
   int raw_coff;
   // split-bf16 weight stream (conv_bf3_kernels.h): [cout/16][nsl][3 planes][64 lanes] x 8 bf16, or null
   const void* wb;
-  int nsl;             // k-slices of 32 = taps * cin_b / 32 + cin2 / 32
-  int cin_b;           // input channels of the split-bf16 stream (cin_real rounded up to 32, zero weights)
+  int nsl;             // k-slices of 32 = taps * cin / 32 + cin2 / 32
   unsigned long long* dbg;   // diagnostic builds only (TRACE_CONV_STAMPS): 16 time stamps per workgroup
-  // Pre-split bf16 PLANE tensors (the conv_bf3_kernel operand format): an fp32
-  // activation x = h + m + l exactly, the three bf16 planes stored as 16-byte cells of 8 consecutive
-  // channels of one position, cell index ((row * 3 + plane) * noct + oct) * L + pos (noct = channels / 8 of
-  // the underlying buffer).  A producer's epilogue writes them next to its fp32 output; a consumer's K loop
-  // copies them global -> LDS with LDS-DMA loads, no registers and no conversion work in between.
-  const void* inp;           // planes of `in` (null: stage from the fp32 tensor)
-  int inp_noct, inp_oct0;
-  const void* in2p;          // planes of `in2`
-  int in2p_noct, in2p_oct0;
-  void* outp;                // planes of `out` to write, or null
-  int outp_noct, outp_oct0;
-  void* rawp;                // planes of `out_raw` to write (GroupNorm-backward epilogue), or null
-  int rawp_noct, rawp_oct0;
-  const void* zero_cell;     // 16 zero bytes in device memory: the source of halo / zero-stuffing cells
   // Split-fp16 K loop (conv_bf3_kernels.h, SCH = 1): operands as TWO fp16 terms, three MFMAs per product.  fp16 has
   // 5 exponent bits, so both operands are brought into range by exact powers of two: the weights on the host
   // (wexp, per layer), the activations per group of 16 trajectories from the largest |value| their PRODUCER saw
@@ -111,9 +84,6 @@ struct ConvArgs {
   const unsigned* in2_amax;
   // Fused head (final block only, cout == 64): pred[row][l][o] = head_b[o] + sum_c head_w[o][c] out[row][c][l], formed
   // from the finished output tile in LDS; `out` may then be null (the activation itself is never read again)
-  // keep_tile: the epilogue stops once the finished activation sits in the LDS output tile (statistics and the saved
-  // raw output are written as usual, `out` is not): conv_block_fwd_kernel stages the block's second conv from it
-  int keep_tile;
   const float* head_w;       // [2][64] or null
   const float* head_b;       // [2]
   float* head_pred;          // [rows][L_OUT][2]
@@ -213,40 +183,6 @@ __device__ __forceinline__ float amax4(float m, const f32x4 y) {
   return fmaxf(fmaxf(m, fmaxf(fabsf(y[0]), fabsf(y[1]))), fmaxf(fabsf(y[2]), fabsf(y[3])));
 }
 
-// The finished 64-channel output tile in LDS ([trajectory][channel][position] fp32) -> plane cells in HBM.
-// One unit = (trajectory, channel octet, position): 8 strided LDS reads (lanes run along positions, so a
-// read is a run of consecutive words), one exact split, three 16-byte stores to consecutive cells.
-template <int L_OUT, int TB, int NTH>
-__device__ __forceinline__ void write_planes(const float* lds, void* planes, const int noct, const int oct_base,
-                                             const int traj0, const int rows) {
-  constexpr int NUNITS = TB * 8 * L_OUT;
-  constexpr int NK = (NUNITS + NTH - 1) / NTH;
-  char* const base = reinterpret_cast<char*>(planes);
-#pragma unroll 1
-  for (int k = 0; k < NK; ++k) {
-    const int u = (int)threadIdx.x + NTH * k;
-    if (u >= NUNITS) break;
-    const int tr = u / (8 * L_OUT);
-    const int r = u - tr * (8 * L_OUT);
-    const int o = r / L_OUT;
-    const int pos = r - o * L_OUT;
-    const float* src = lds + (tr * 64 + o * 8) * L_OUT + pos;
-    float v[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[j * L_OUT];
-    u32x4v h, m, l;
-    split8_bf16(v, h, m, l);
-    const int row = traj0 + tr;
-    if (row < rows) {
-      const size_t pstride = (size_t)noct * L_OUT * 16;                          // bytes between planes
-      char* dst = base + (((size_t)row * 3 * noct + (oct_base + o)) * L_OUT + pos) * 16;
-      *reinterpret_cast<u32x4v*>(dst) = h;
-      *reinterpret_cast<u32x4v*>(dst + pstride) = m;
-      *reinterpret_cast<u32x4v*>(dst + 2 * pstride) = l;
-    }
-  }
-}
-
 #ifdef TRACE_CONV_STAMPS
 #define TRACE_STAMP(i)                                                                \
   do {                                                                                \
@@ -309,7 +245,7 @@ __device__ __forceinline__ void group_sum(float (&v)[NP], int cg) {
   }
 }
 
-// ---- epilogue (shared by the fp32 and the split-bf16 K loops) ------------------------------
+// ---- epilogue --------------------------------------------------------------------------------
 // The 208 x 64 accumulator tile of a workgroup (wave w owns output channels 16w .. 16w+15 and all
 // NRT row tiles, MFMA C layout: column = lane & 15, rows 4 (lane >> 4) + reg) goes through LDS once,
 // laid out exactly like the global tensors ([trajectory][channel][position], TILE floats per
@@ -452,18 +388,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     }
     if (a.raw_amax && a.out_raw) record_amax(a.raw_amax, traj0, mraw);
     if (!normed) {                             // uniform per workgroup
-      if (a.rawp) {
-        __syncthreads();
-        write_planes<L_OUT, TB, NTH>(lds, a.rawp, a.rawp_noct, a.rawp_oct0 + (co0 >> 3), traj0, a.rows);
-      }
       TRACE_STAMP(11);
       return;
     }
     __syncthreads();
-    if (a.rawp) {                              // the raw gradient's planes, before the rows are normalised in place
-      write_planes<L_OUT, TB, NTH>(lds, a.rawp, a.rawp_noct, a.rawp_oct0 + (co0 >> 3), traj0, a.rows);
-      __syncthreads();
-    }
     // G2 (rows): thread = one (trajectory, channel) row per pass, lanes = channels; with more waves than
     // trajectories (L = 52 on 8 waves) the upper waves have no row
     if (TB >= NW || wave < TB) {
@@ -553,8 +481,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
       mout = amax4(mout, y);
     }
     if (a.out_amax) record_amax(a.out_amax, traj0, mout);
-    if (a.outp)                                // the tile still holds d/dy
-      write_planes<L_OUT, TB, NTH>(lds, a.outp, a.outp_noct, a.outp_oct0 + (co0 >> 3), traj0, a.rows);
     TRACE_STAMP(11);
     return;
   }
@@ -693,7 +619,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
   if (has_tab) __syncthreads();
   TRACE_STAMP(9);
 
-  if (a.keep_tile) return;
   // Fused head: the tile holds the finished activation (no residual on this layer); one (trajectory, position) per
   // thread, the 64 channels in the order and with the FMAs of head_fwd_kernel (same bits)
   if (a.head_pred) {
@@ -724,474 +649,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     y += rv[k];
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
     mout = amax4(mout, y);
-    if (a.outp && flat_live(k)) *reinterpret_cast<f32x4*>(lds_cell(k)) = y;      // the finished value, for the planes
-  }
-  if (a.out_amax) record_amax(a.out_amax, traj0, mout);
-  if (a.outp) {
-    __syncthreads();
-    write_planes<L_OUT, TB, NTH>(lds, a.outp, a.outp_noct, a.outp_oct0 + (co0 >> 3), traj0, a.rows);
-  }
-  TRACE_STAMP(11);
-}
-
-// ---- forward epilogue of the trajectory-major tiles (conv_bf3_kernel), statistics in registers ----
-// In the trajectory-major accumulator layout every lane holds COMPLETE (trajectory, channel) rows:
-// channel = 16 wave + (lane & 15); with PPT = L_OUT / 13 positions per row tile a lane owns
-// NPR = 4 / PPT trajectories (q NPR + j, q = lane >> 4), row j = registers j PPT .. j PPT + PPT - 1 of all 13
-// accumulator tiles.  GroupNorm moments, normalisation, Mish and the condition add therefore run on
-// the accumulators before they leave the registers: the tile goes through LDS once, finished
-// (twice when the raw conv output is saved for the backward).  Groups of 8 / 16 channels reduce inside
-// the wave's 16-lane rows (DPP); groups of 32 channels span two waves and exchange their 16-channel
-// partial sums through 512 B of LDS behind the tile.
-template <int L_OUT, int TB>
-__device__ __forceinline__ void conv_epilogue_fwd_rows(const ConvArgs& a, f32x4 (&acc)[TB * L_OUT / 16],
-                                                       float* lds, const int traj0, const int co0,
-                                                       const float oscale = 1.f) {
-  constexpr int R = TB * L_OUT, NRT = R / 16, PPT = L_OUT / NRT, NPR = 4 / PPT;
-  constexpr int TILE = 64 * L_OUT;
-  constexpr int NQ = R * 64 / 4 / 256;
-  static_assert(PPT * NRT == L_OUT && PPT * TB == 16 && (PPT == 1 || PPT == 2 || PPT == 4), "bad tile");
-  typedef unsigned u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  const int col = lane & 15, q = lane >> 4;
-  const int co_l = wave * 16 + col, co = co0 + co_l;
-  const bool has_tab = a.gn || a.pc;
-  auto flat_off = [&](int k, int tstride, int coff) -> unsigned {
-    const int f = (tid + 256 * k) * 4;
-    const int tr = f / TILE;
-    const int rem = f - tr * TILE;
-    const int tg = traj0 + tr;
-    return tg < a.rows ? ((unsigned)tg * (unsigned)tstride + (unsigned)((coff + co0) * L_OUT + rem)) * 4u
-                       : 0xffffffffu;
-  };
-  f32x4 rv[NQ];
-  if (a.res) {
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.res), 0, (unsigned)((size_t)a.rows * a.res_tstride * sizeof(float)), 0x00020000);
-#pragma unroll
-    for (int k = 0; k < NQ; ++k)
-      rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rr, flat_off(k, a.res_tstride, a.res_coff), 0, 0));
-  } else {
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-  if (a.res2) {
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.res2), 0, (unsigned)((size_t)a.rows * a.res2_tstride * sizeof(float)), 0x00020000);
-#pragma unroll
-    for (int k = 0; k < NQ; ++k)
-      rv[k] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                             rr, flat_off(k, a.res2_tstride, a.res2_coff), 0, 0));
-  }
-
-  {  // conv bias
-    const float bv = a.bias ? a.bias[co] : 0.f;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      acc[rt][0] = fmaf(acc[rt][0], oscale, bv); acc[rt][1] = fmaf(acc[rt][1], oscale, bv);
-      acc[rt][2] = fmaf(acc[rt][2], oscale, bv); acc[rt][3] = fmaf(acc[rt][3], oscale, bv);
-    }
-  }
-  // accumulators -> tile laid out like the global tensor ([trajectory][channel][position])
-  auto write_tile = [&]() {
-    float* tcol = lds + co_l * L_OUT;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) {
-      const f32x4 v = acc[rt];
-      if constexpr (PPT == 4) {
-        *reinterpret_cast<f32x4*>(tcol + q * TILE + 4 * rt) = v;
-      } else if constexpr (PPT == 2) {
-        *reinterpret_cast<float2*>(tcol + (2 * q) * TILE + 2 * rt) = float2{v[0], v[1]};
-        *reinterpret_cast<float2*>(tcol + (2 * q + 1) * TILE + 2 * rt) = float2{v[2], v[3]};
-      } else {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) tcol[(4 * q + reg) * TILE + rt] = v[reg];
-      }
-    }
-  };
-  if (a.ysave) {
-    __syncthreads();                       // every wave is out of the K loop's LDS image
-    write_tile();
-    __syncthreads();
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        a.ysave, 0, (unsigned)((size_t)a.rows * a.cout * L_OUT * sizeof(float)), 0x00020000);
-#pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      const f32x4 y = *reinterpret_cast<const f32x4*>(lds + (tid + 256 * k) * 4);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ry, flat_off(k, a.cout * L_OUT, 0), 0, 0);
-    }
-  }
-  TRACE_STAMP(10);
-
-  if (has_tab) {
-    const float gam = a.gn ? a.gamma[co] : 1.f;
-    const float bet = a.gn ? a.beta[co] : 0.f;
-    const float ptv = a.pc ? a.pt[co] : 0.f;
-    const int cg = a.gn ? a.cg : 1;
-    float add[NPR], scale[NPR], shift[NPR];
-#pragma unroll
-    for (int j = 0; j < NPR; ++j) {
-      const int tg = min(traj0 + q * NPR + j, a.rows - 1);
-      add[j] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
-      scale[j] = 1.f;
-      shift[j] = 0.f;
-    }
-    if (a.gn) {
-      float rmean[NPR], m2[NPR], gs[NPR], gv[NPR];
-#pragma unroll
-      for (int j = 0; j < NPR; ++j) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-          for (int e = 0; e < PPT; ++e) sacc += acc[rt][j * PPT + e];
-        const float rm = sacc * (1.f / (float)L_OUT);
-        float qq = 0.f;
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-          for (int e = 0; e < PPT; ++e) {
-            const float d = acc[rt][j * PPT + e] - rm;
-            qq = fmaf(d, d, qq);
-          }
-        rmean[j] = rm;
-        m2[j] = qq;
-        gs[j] = rm;
-      }
-      TRACE_STAMP(6);
-      // two waves' 16-channel partial sums -> the 32-channel group (both waves add in the same order)
-      float* xch = lds + R * 64;            // [round][wave][TB]
-      auto pair_sum = [&](float (&v)[NPR], int round) {
-        if (col == 0) {
-#pragma unroll
-          for (int j = 0; j < NPR; ++j) xch[(round * 4 + wave) * TB + q * NPR + j] = v[j];
-        }
-        __syncthreads();
-        const int w0 = wave & ~1;
-#pragma unroll
-        for (int j = 0; j < NPR; ++j)
-          v[j] = xch[(round * 4 + w0) * TB + q * NPR + j] + xch[(round * 4 + w0 + 1) * TB + q * NPR + j];
-      };
-      group_sum<NPR>(gs, cg < 16 ? cg : 16);
-      if (cg > 16) pair_sum(gs, 0);
-#pragma unroll
-      for (int j = 0; j < NPR; ++j) {
-        gs[j] = gs[j] / (float)cg;                       // group mean
-        const float dm = rmean[j] - gs[j];
-        gv[j] = fmaf(dm * dm, (float)L_OUT, m2[j]);
-      }
-      group_sum<NPR>(gv, cg < 16 ? cg : 16);
-      if (cg > 16) pair_sum(gv, 1);
-      TRACE_STAMP(7);
-#pragma unroll
-      for (int j = 0; j < NPR; ++j) {
-        const int tr = q * NPR + j;
-        const float mean = gs[j];
-        const float var = gv[j] / (float)(cg * L_OUT);
-        const float rstd = 1.f / sqrtf(var + 1e-5f);
-        scale[j] = rstd * gam;
-        shift[j] = bet - mean * scale[j];
-        if (a.stats && (co & (cg - 1)) == 0 && traj0 + tr < a.rows) {
-          const int cgs = __builtin_ctz(cg);
-          const size_t si = ((size_t)(traj0 + tr) * (a.cout >> cgs) + (co >> cgs)) * 2;
-          a.stats[si] = mean;
-          a.stats[si + 1] = rstd;
-        }
-      }
-    }
-    TRACE_STAMP(8);
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt)
-#pragma unroll
-      for (int j = 0; j < NPR; ++j)
-#pragma unroll
-        for (int e = 0; e < PPT; ++e) {
-          float z = fmaf(acc[rt][j * PPT + e], scale[j], shift[j]);
-          if (a.gn) z = mish_fast_f(z);
-          acc[rt][j * PPT + e] = z + add[j];
-        }
-  }
-  __syncthreads();                          // K-loop image / raw tile fully read
-  write_tile();
-  __syncthreads();
-  TRACE_STAMP(9);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(
-      a.out, 0, (unsigned)((size_t)a.rows * a.out_tstride * sizeof(float)), 0x00020000);
-  float mout = 0.f;
-#pragma unroll
-  for (int k = 0; k < NQ; ++k) {
-    f32x4 y = *reinterpret_cast<const f32x4*>(lds + (tid + 256 * k) * 4);
-    y += rv[k];
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, flat_off(k, a.out_tstride, a.out_coff), 0, 0);
-    mout = amax4(mout, y);
   }
   if (a.out_amax) record_amax(a.out_amax, traj0, mout);
   TRACE_STAMP(11);
-}
-
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
-struct ConvGeom {
-  static constexpr int R = TB * L_OUT;
-  static constexpr int NRT = R / 16;
-  static constexpr int LP = (L_OUT - 1) * IN_STRIDE + TAPS;
-  static constexpr int S = TB * LP;                        // staged positions (with halo)
-  static constexpr int CHS = CH + 4;                       // LDS floats per position: CHS/4 odd
-  static constexpr int L_IN = (L_OUT * IN_STRIDE) / UP;
-  static constexpr int RS = R + 4;
-  static constexpr int F4_PER_TRAJ = CH * L_IN / 4;        // float4 per trajectory per chunk
-  static constexpr int F4_TOTAL = TB * F4_PER_TRAJ;
-  static constexpr int NF4 = (F4_TOTAL + 255) / 256;       // staging registers (float4) per thread
-  static constexpr int KBPC = CH / 16;
-  static constexpr int NKK = TAPS * KBPC;
-  static_assert(R % 16 == 0, "row block must be a whole number of MFMA tiles");
-  static_assert((CH * L_IN) % 4 == 0 && CH % 16 == 0, "chunk must be float4 / k-block aligned");
-  static_assert((CHS / 4) % 2 == 1, "position stride must be an odd number of 16-byte slots");
-  static constexpr int NQ = R * 64 / 4 / 256;              // output float4 per thread
-  static_assert(R * 64 % 1024 == 0 && TB % 4 == 0, "output tile must split evenly over 256 threads");
-  static constexpr size_t EPI_FLOATS = (size_t)R * 64;                         // the output tile
-  static constexpr size_t LDS_FLOATS = ((size_t)CHS * S > EPI_FLOATS) ? (size_t)CHS * S : EPI_FLOATS;
-};
-
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs a) {
-  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
-  constexpr int NRT = G::NRT, LP = G::LP, S = G::S, L_IN = G::L_IN, CHS = G::CHS;
-  constexpr int NF4 = G::NF4, KBPC = G::KBPC, NKK = G::NKK;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
-  // Workgroup id -> (row block, column tile).  Consecutive ids go round-robin over the 8 XCDs
-  // (id % 8), each with its own L2, so the ncol column tiles of one row block -- which all stage
-  // the same activations -- are given ids of the same residue, 8 apart: they run at the same time
-  // behind the same L2 and the input comes from HBM once instead of ncol times.
-  const int ncol = a.cout >> 6;
-  const int bid = blockIdx.x;
-  const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
-  const int ct = (bid >> 3) % ncol;
-  if (rb * TB >= a.rows) return;               // padding ids of the last group of 8 row blocks
-  const int traj0 = rb * TB;
-  const int co0 = ct * 64;
-  TRACE_STAMP(0);
-#ifdef TRACE_CONV_STAMPS
-  if (a.dbg && threadIdx.x == 0) {
-    a.dbg[(size_t)blockIdx.x * 16 + 12] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
-    a.dbg[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
-  }
-#endif
-
-  // ---- staging: thread handles float4 #(tid + 256 j) of the chunk -------------------------
-  // Buffer loads with a 32-bit byte offset: the descriptor's range check returns 0 for
-  // trajectories past `rows` (tail workgroup), so there is no per-load predicate.
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in), 0, (unsigned)((size_t)a.rows * a.in_tstride * sizeof(float)),
-      0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.in2 ? a.in2 : a.in), 0,
-      a.in2 ? (unsigned)((size_t)a.rows * a.in2_tstride * sizeof(float)) : 0u, 0x00020000);
-  const int nch1 = a.cin / CH;
-  const int nch = nch1 + a.cin2 / CH;
-  unsigned spk[NF4];            // (trajectory in tile) << 20 | float offset inside the chunk
-#pragma unroll
-  for (int j = 0; j < NF4; ++j) {
-    const int q = tid + 256 * j;
-    const int tr = q / G::F4_PER_TRAJ;
-    const int rem = q - tr * G::F4_PER_TRAJ;
-    spk[j] = q < G::F4_TOTAL ? ((unsigned)tr << 20) | (unsigned)(rem * 4) : 0xffffffffu;
-  }
-  f32x4 stg[NF4];
-  auto stage_load = [&](int ch) {
-    const bool second = ch >= nch1;
-    const int tstride = second ? a.in2_tstride : a.in_tstride;
-    const int cbase = ((second ? a.in2_coff + (ch - nch1) * CH : a.in_coff + ch * CH) * L_IN) +
-                      traj0 * tstride;
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const unsigned off = spk[j] == 0xffffffffu
-                               ? 0xffffffffu     // out of range -> zeros
-                               : ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u;
-      auto v = second ? __builtin_amdgcn_raw_buffer_load_b128(rsrc2, off, 0, 0)
-                      : __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
-      stg[j] = __builtin_bit_cast(f32x4, v);
-    }
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int j = 0; j < NF4; ++j) {
-      const int q = tid + 256 * j;
-      if (q < G::F4_TOTAL) {
-        const int tr = q / G::F4_PER_TRAJ;
-        const int e0 = (q - tr * G::F4_PER_TRAJ) * 4;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u;
-          const int ci = e / L_IN;
-          const int i = e - ci * L_IN;
-          lds[(tr * LP + i * UP + PADL) * CHS + ci] = stg[j][u];
-        }
-      }
-    }
-  };
-
-  stage_load(0);
-  // halo / zero-stuffing positions are written once; data positions are the same for every chunk
-  if constexpr (UP == 1 && IN_STRIDE == 1 && TAPS == 1) {
-    // 1x1 conv: no halo, every position is overwritten by stage_write
-  } else if constexpr (UP == 1 && IN_STRIDE == 1) {
-    // every data position is overwritten by stage_write: only the TAPS-1 halo positions per
-    // trajectory need zeros
-    constexpr int HALO = LP - L_IN;                     // = TAPS - 1, PADL of them in front
-    constexpr int Q = CHS / 4;
-    for (int i = tid; i < TB * HALO * Q; i += 256) {
-      const int tr = i / (HALO * Q);
-      const int r = i - tr * (HALO * Q);
-      const int h = r / Q;
-      const int pos = tr * LP + (h < PADL ? h : L_IN + h);
-      reinterpret_cast<f32x4*>(lds)[pos * Q + (r - h * Q)] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-  } else {
-#pragma unroll 2
-    for (int i = tid; i < CHS * S / 4; i += 256)
-      reinterpret_cast<f32x4*>(lds)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-
-  // LDS image is [position][channel]; lane (row = lane&15, kq = lane>>4) reads the 4 channels
-  // 16m + 4kq .. +3 of its output row's input position with one ds_read_b128, and feeds element
-  // u to MFMA pass u (the host packs the weights in the matching k order)
-  int rowoff[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) {
-    int r = rt * 16 + (lane & 15);
-    int tr = r / L_OUT;
-    int l = r - tr * L_OUT;
-    rowoff[rt] = (tr * LP + l * IN_STRIDE) * CHS + (lane >> 4) * 4;
-  }
-  f32x4 acc[NRT];
-#pragma unroll
-  for (int rt = 0; rt < NRT; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const f32x4* wp = a.wp + ((size_t)(ct * 4 + wave) * a.nkb) * 64 + lane;
-  f32x4 bnext = *wp;
-  f32x4 bnext2 = a.nkb > 1 ? wp[64] : bnext;
-  int kdone = 0;
-
-  TRACE_STAMP(14);
-  for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();            // previous chunk fully consumed (and zero fill done)
-    stage_write();
-    if (ch == 0) TRACE_STAMP(15);
-    if (ch + 1 < nch) stage_load(ch + 1);       // in flight during this chunk's K loop
-    __syncthreads();
-
-    // K loop over the staged chunk.  One ds_read_b128 per (row tile, k-block) supplies the A
-    // values of 4 MFMA passes; the read for the NEXT k-block is issued right after the last pass
-    // that consumes the register, i.e. 13 MFMAs (>400 cycles) ahead of its first use.
-    // Chunks of the second source contribute at the centre tap only.
-    if (ch == 0) TRACE_STAMP(1);
-    const bool second = ch >= nch1;
-    int kk = second ? PADL * KBPC : 0;
-    const int kk_end = second ? (PADL + 1) * KBPC : NKK;
-    int tap = second ? PADL : 0, kb = 0;
-    f32x4 av[NRT];
-    const float* lp = lds + tap * CHS;
-#pragma unroll
-    for (int rt = 0; rt < NRT; ++rt) av[rt] = *reinterpret_cast<const f32x4*>(lp + rowoff[rt]);
-    for (; kk < kk_end; ++kk) {
-      const f32x4 b = bnext;
-      bnext = bnext2;
-      ++kdone;
-      wp += 64;
-      if (kdone + 1 < a.nkb) bnext2 = wp[64];
-      int kb2 = kb + 1, tap2 = tap;
-      if (kb2 == KBPC) { kb2 = 0; ++tap2; }
-      const float* lpn = lds + tap2 * CHS + kb2 * 16;
-      const bool more = kk + 1 < kk_end;
-#pragma unroll
-      for (int u = 0; u < 3; ++u) {
-#pragma unroll
-        for (int rt = 0; rt < NRT; ++rt)
-          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][u], b[u], acc[rt], 0, 0, 0);
-      }
-#pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) {
-        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[rt][3], b[3], acc[rt], 0, 0, 0);
-        if (more) av[rt] = *reinterpret_cast<const f32x4*>(lpn + rowoff[rt]);
-      }
-      lp = lpn;
-      kb = kb2;
-      tap = tap2;
-    }
-    if (ch < 4) TRACE_STAMP(2 + ch);
-  }
-
-  conv_epilogue<L_OUT, TB>(a, acc, lds, traj0, co0);
-}
-
-template <int L_OUT, int IN_STRIDE, int UP, int TAPS, int PADL, int TB, int CH>
-int launch_conv(const ConvArgs& a_in, hipStream_t st) {
-  using G = ConvGeom<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>;
-  ConvArgs a = a_in;
-  if (a.rows <= 0) return TRACE_OK;
-  TRACE_REQUIRE(a.cout % 64 == 0 && a.chunk == CH && a.cin % CH == 0 && a.cin2 % CH == 0 &&
-                    a.nkb == TAPS * a.cin / 16 + a.cin2 / 16,
-                "conv: bad channel geometry cin=%d cin2=%d chunk=%d cout=%d nkb=%d", a.cin, a.cin2,
-                a.chunk, a.cout, a.nkb);
-  TRACE_REQUIRE(a.cin2 == 0 || (a.in2 && IN_STRIDE == 1 && UP == 1 && a.in2_tstride % 4 == 0 &&
-                                a.in2_coff % 16 == 0 && (reinterpret_cast<uintptr_t>(a.in2) & 15) == 0 &&
-                                (size_t)(a.rows + TB) * a.in2_tstride * sizeof(float) < 0xffffffffull),
-                "conv: second K source needs a stride-1 conv and an aligned tensor below 4 GiB");
-  TRACE_REQUIRE(!a.gnb || (!a.gn && !a.pc && !a.ysave && a.gb_y && a.gb_stats && a.gb_gamma && a.gb_beta &&
-                           a.gb_cg > 0 && (a.gb_cg & (a.gb_cg - 1)) == 0 && a.gb_cg <= 64 &&
-                           a.gb_cmax % 64 == 0 && a.gb_cmax <= a.gb_c &&
-                           (reinterpret_cast<uintptr_t>(a.gb_y) & 15) == 0),
-                "conv: bad GroupNorm-backward epilogue arguments");
-  TRACE_REQUIRE(!a.gn || (a.cg > 0 && (a.cg & (a.cg - 1)) == 0 && a.cg <= 64), "conv: group size %d",
-                a.cg);
-  TRACE_REQUIRE(a.in_tstride % 4 == 0 && a.in_coff % 16 == 0 &&
-                    (reinterpret_cast<uintptr_t>(a.in) & 15) == 0,
-                "conv: input must be 16-byte aligned per trajectory chunk");
-  TRACE_REQUIRE((size_t)(a.rows + TB) * a.in_tstride * sizeof(float) < 0xffffffffull,
-                "conv: input of %d rows exceeds the 4 GiB buffer-descriptor range; split the rows",
-                a.rows);
-  // the epilogue moves 4 consecutive outputs per access through buffer descriptors
-  auto ok128 = [&](const float* p, int tstride, int coff) {
-    return p == nullptr || ((reinterpret_cast<uintptr_t>(p) & 15) == 0 && tstride % 4 == 0 &&
-                            (coff * L_OUT) % 4 == 0 &&
-                            (size_t)a.rows * tstride * sizeof(float) < 0xffffffffull);
-  };
-  TRACE_REQUIRE(ok128(a.out, a.out_tstride, a.out_coff) && ok128(a.res, a.res_tstride, a.res_coff) &&
-                    ok128(a.res2, a.res2_tstride, a.res2_coff) && ok128(a.ysave, a.cout * L_OUT, 0) &&
-                    ok128(a.out_raw, a.raw_tstride, a.raw_coff),
-                "conv: output / residual tensors must be 16-byte aligned per trajectory tile and "
-                "below 4 GiB (%d rows)", a.rows);
-  TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
-  constexpr size_t lds_bytes = G::LDS_FLOATS * sizeof(float);
-  // two workgroups per CU must fit in the 160 KiB LDS
-  static_assert(lds_bytes <= 80 * 1024, "conv: LDS per workgroup too large");
-  static unsigned long long attr_done = 0;      // one bit per device
-  if (first_launch_on_device(&attr_done)) {
-    TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  }
-  const int nrb = (a.rows + TB - 1) / TB;
-  dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 64));
-#ifdef TRACE_CONV_STAMPS
-  a.dbg = stamp_buffer_for_next_launch();
-#endif
-  const bool prof = prof_active();
-  if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_gemm_kernel<L_OUT, IN_STRIDE, UP, TAPS, PADL, TB, CH>), grid, dim3(256),
-                     lds_bytes, st, a);
-  if (prof) {
-    const double fl = 2.0 * a.alg_macs_per_pos * (double)a.rows * L_OUT;
-    prof_post(st, fl, fl / PEAK_MFMA32_FLOPS);
-  }
-  return launch_status("conv_gemm_kernel");
 }
 
 }  // namespace trace

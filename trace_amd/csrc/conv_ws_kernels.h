@@ -675,11 +675,9 @@ int conv_ws_num_cus();                       // unet.hip: multiprocessor count o
 
 template <int L_OUT, int UP, int TAPS, int PADL, int TB>
 int launch_conv_ws(const ConvArgs& a_in, hipStream_t st) {
-  using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, 4>;
   using W = WsGeom<L_OUT, UP, TAPS, PADL, TB>;
   ConvArgs a = a_in;
   if (a.rows <= 0) return TRACE_OK;
-  TRACE_REQUIRE(!a.outp && !a.rawp, "conv(ws): plane outputs are not supported");
   TRACE_REQUIRE(a.wb && a.cout % 64 == 0 && a.cin % 32 == 0 && a.cin2 % 32 == 0 &&
                     a.nsl == TAPS * a.cin / 32 + a.cin2 / 32 && a.cin / 32 + a.cin2 / 32 >= 2 &&
                     (a.cin / 32 + a.cin2 / 32) % 2 == 0,

@@ -15,8 +15,7 @@ int conv_ws_mode(int mode) {
   static int cur = -1;
   int prev = __atomic_load_n(&cur, __ATOMIC_ACQUIRE);
   if (prev < 0) {
-    const char* e = getenv("TRACE_CONV_WS");
-    prev = e ? (atoi(e) != 0) : TRACE_CONV_WS_DEFAULT;
+    prev = 0;
     __atomic_store_n(&cur, prev, __ATOMIC_RELEASE);
   }
   if (mode >= 0) __atomic_store_n(&cur, mode != 0, __ATOMIC_RELEASE);
@@ -25,22 +24,16 @@ int conv_ws_mode(int mode) {
 
 // Operand scheme of the implicit-GEMM convs: 1 (default) = two fp16 terms / three MFMAs per product wherever a
 // launch has the scales of all its operands (conv_bf3_kernels.h, SCH = 1), 0 = three bf16 terms / six MFMAs
-// everywhere.  TRACE_CONV_SCHEME=bf16x3 | fp16x2 presets it; returns the previous value.
+// everywhere (trace_conv_scheme; tests/test_gpu_full_size.py compares the two).  Returns the previous value.
 int conv_scheme(int mode) {
   static int cur = -1;
   int prev = __atomic_load_n(&cur, __ATOMIC_ACQUIRE);
   if (prev < 0) {
-    const char* e = getenv("TRACE_CONV_SCHEME");
-    prev = e ? (strcmp(e, "bf16x3") == 0 || strcmp(e, "0") == 0 ? 0 : 1) : 1;
+    prev = 1;
     __atomic_store_n(&cur, prev, __ATOMIC_RELEASE);
   }
   if (mode >= 0) __atomic_store_n(&cur, mode != 0, __ATOMIC_RELEASE);
   return prev;
-}
-
-bool force_fp32_convs() {
-  static const bool v = [] { const char* e = getenv("TRACE_CONV_FP32"); return e && e[0] == '1'; }();
-  return v;
 }
 
 bool prof_stamping() {
@@ -299,17 +292,13 @@ using namespace trace;
 namespace {
 
 struct PackedConv {
-  f32x4* w = nullptr;  // device, [cout/16][nkb][64]
-  int cin = 0;         // padded
+  int cin = 0;         // input channels of the streams: cin_real rounded up to 32 (zero weights)
   int cin_real = 0;
   int cout = 0;
   int taps = 0;
-  int chunk = 0;
-  int nkb = 0;
   int cin2 = 0;        // channels of the appended centre-tap source
-  void* wb = nullptr;  // device, split-bf16 stream [cout/16][nsl][3][64] x 8 bf16 (null: fp32 kernel only)
-  int nsl = 0;
-  int cin_b = 0;       // input channels of that stream: cin_real rounded up to 32 (zero weights)
+  void* wb = nullptr;  // device, split-bf16 stream [cout/16][nsl][3][64] x 8 bf16
+  int nsl = 0;         // k-slices of 32 = taps * cin / 32 + cin2 / 32
   void* wh = nullptr;  // device, split-fp16 stream [cout/16][nsl][2][64] x 8 fp16 of the weights times 2^wexp
   int wexp = 0;        // the layer's largest |weight| times 2^wexp lies in [2^13, 2^14)
 };
@@ -351,25 +340,16 @@ struct trace_unet {
   // buffer plan (floats per row)
   std::vector<int> buf_floats;
   std::vector<char> buf_save_only;
-  std::vector<int> buf_twin;      // id of the buffer holding the pre-split bf16 planes of this one, or -1
-  void* zero_cell = nullptr;      // 16 zero bytes (halo source of the plane staging)
-  // second stream + fork / join events: large calls run the two halves of their rows side by side (run_split)
-  hipStream_t side[3] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+  // second stream + fork / join events: large calls run the two halves of their rows side by side (run_split);
+  // `busy` makes that one call at a time per model (a concurrent call stays on its own stream)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int busy = 0;
 
-  // planes: the activation is a conv input -> a twin buffer of 3 bf16 planes (6 bytes per element)
-  int new_buf(int floats, bool save_only, bool planes = false) {
+  int new_buf(int floats, bool save_only) {
     buf_floats.push_back(floats);
     buf_save_only.push_back(save_only ? 1 : 0);
-    buf_twin.push_back(-1);
-    const int id = (int)buf_floats.size() - 1;
-    if (planes) {
-      buf_floats.push_back(floats + floats / 2);
-      buf_save_only.push_back(save_only ? 1 : 0);
-      buf_twin.push_back(-1);
-      buf_twin[id] = id + 1;
-    }
-    return id;
+    return (int)buf_floats.size() - 1;
   }
   // ids
   std::vector<int> b_h1, b_out, b_res, b_y1, b_y2, b_s1, b_s2;
@@ -389,53 +369,23 @@ int upload(trace_unet* u, const std::vector<T>& h, T** out) {
   return TRACE_OK;
 }
 
-// get(tap, ci, co) -> weight of the GEMM B matrix; ci >= cin_real returns 0.
+// get(tap, ci, co) -> weight of the GEMM B matrix; ci >= cin_real is zero weight.
 // Optional second K source (cin2 channels, one tap): get2(ci2, co), appended after the first.
-int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
+int pack_conv(trace_unet* u, int cin_real, int cout, int taps,
               const std::function<float(int, int, int)>& get, PackedConv* pc, int cin2 = 0,
               const std::function<float(int, int)>& get2 = nullptr) {
-  int cin = ((cin_real + chunk - 1) / chunk) * chunk;
-  if (cin_real <= 48 && cin_real % 16 != 0) {  // first layer: 38 -> 48, single chunk
-    cin = ((cin_real + 15) / 16) * 16;
-    chunk = cin;
-  }
-  if (cin2 % chunk != 0) {
-    set_error("pack_conv: second source of %d channels is not a multiple of the chunk %d", cin2, chunk);
+  if (cin2 % 32 != 0 || cout % 64 != 0) {
+    set_error("pack_conv: cin2 = %d / cout = %d are not multiples of 32 / 64", cin2, cout);
     return TRACE_EINVAL;
   }
-  int nkb = taps * cin / 16 + cin2 / 16;
-  int kbpc = chunk / 16;
-  std::vector<float> h((size_t)(cout / 16) * nkb * 64 * 4, 0.f);
-  for (int ct = 0; ct < cout / 16; ++ct) {
-    int kblk = 0;
-    auto put = [&](int c0, int tap, bool second) {
-      for (int kb = 0; kb < kbpc; ++kb, ++kblk)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int s = 0; s < 4; ++s) {
-            int ci = c0 + kb * 16 + (lane >> 4) * 4 + s;   // pass s of lane group kq = lane>>4
-            int co = ct * 16 + (lane & 15);
-            float v = second ? get2(ci, co) : (ci < cin_real ? get(tap, ci, co) : 0.f);
-            h[(((size_t)ct * nkb + kblk) * 64 + lane) * 4 + s] = v;
-          }
-    };
-    for (int c0 = 0; c0 < cin; c0 += chunk)
-      for (int tap = 0; tap < taps; ++tap) put(c0, tap, false);
-    for (int c0 = 0; c0 < cin2; c0 += chunk) put(c0, 0, true);
-  }
-  float* d = nullptr;
-  int rc = upload(u, h, &d);
-  if (rc) return rc;
-  pc->w = reinterpret_cast<f32x4*>(d);
-  pc->cin = cin;
+  int rc = TRACE_OK;
   pc->cin_real = cin_real;
   pc->cout = cout;
   pc->taps = taps;
-  pc->chunk = chunk;
-  pc->nkb = nkb;
   pc->cin2 = cin2;
   // split-bf16 stream for conv_bf3_kernel: slices of 32 channels, chunk-major then tap, the second
   // source appended; every weight as three bf16 terms h + m + l (round-to-nearest each)
-  if (cin2 % 32 == 0) {
+  {
     const int cin_b = (cin_real + 31) / 32 * 32;
     auto bf16_rne = [](float v) -> uint16_t {
       uint32_t x;
@@ -479,7 +429,7 @@ int pack_conv(trace_unet* u, int cin_real, int cout, int taps, int chunk,
     if (rc) return rc;
     pc->wb = db;
     pc->nsl = nsl;
-    pc->cin_b = cin_b;
+    pc->cin = cin_b;
     // split-fp16 stream, same slice order: w 2^wexp = h + l, both fp16 (round-to-nearest), wexp from the layer's
     // largest |w| so that every low term of a weight within 2^-10 of it is a normal fp16
     float wmax = 0.f;
@@ -613,10 +563,8 @@ extern "C" void trace_unet_destroy(trace_unet* u) {
   if (!u) return;
   for (void* p : u->allocs) (void)hipFree(p);
   if (u->ev_fork) (void)hipEventDestroy(u->ev_fork);
-  for (int i = 0; i < 3; ++i) {
-    if (u->ev_join[i]) (void)hipEventDestroy(u->ev_join[i]);
-    if (u->side[i]) (void)hipStreamDestroy(u->side[i]);
-  }
+  if (u->ev_join) (void)hipEventDestroy(u->ev_join);
+  if (u->side) (void)hipStreamDestroy(u->side);
   delete u;
 }
 
@@ -680,10 +628,10 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
     const float* g2 = cur.take(b.cout);
     const float* be2 = cur.take(b.cout);
     const int ci_ = b.cin, co_ = b.cout;
-    TRY(pack_conv(u, ci_, co_, 5, 64, [=](int tap, int ci, int co) { return w1[((size_t)co * ci_ + ci) * 5 + tap]; }, &b.c1f));
-    TRY(pack_conv(u, co_, co_, 5, 64, [=](int tap, int ci, int co) { return w2[((size_t)co * co_ + ci) * 5 + tap]; }, &b.c2f));
+    TRY(pack_conv(u, ci_, co_, 5, [=](int tap, int ci, int co) { return w1[((size_t)co * ci_ + ci) * 5 + tap]; }, &b.c1f));
+    TRY(pack_conv(u, co_, co_, 5, [=](int tap, int ci, int co) { return w2[((size_t)co * co_ + ci) * 5 + tap]; }, &b.c2f));
     // dgrad: K runs over (tap', co), output channel = ci, weight W[co][ci][4 - tap']
-    TRY(pack_conv(u, co_, co_, 5, 64, [=](int tap, int k, int n) { return w2[((size_t)k * co_ + n) * 5 + (4 - tap)]; }, &b.c2b));
+    TRY(pack_conv(u, co_, co_, 5, [=](int tap, int k, int n) { return w2[((size_t)k * co_ + n) * 5 + (4 - tap)]; }, &b.c2b));
     if (bi == 0) first_w1 = w1;
     TRY(upload_vec(u, b1, co_, &b.b1));
     TRY(upload_vec(u, g1, co_, &b.g1));
@@ -694,16 +642,16 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
     if (b.has_res) {
       const float* wr = cur.take((int64_t)co_ * ci_);
       const float* br = cur.take(co_);
-      TRY(pack_conv(u, ci_, co_, 1, 64, [=](int, int ci, int co) { return wr[(size_t)co * ci_ + ci]; }, &b.rf));
+      TRY(pack_conv(u, ci_, co_, 1, [=](int, int ci, int co) { return wr[(size_t)co * ci_ + ci]; }, &b.rf));
       // input-VJP: the 1x1 residual conv's dgrad rides in the k5 dgrad as extra K (centre tap)
       if (bi > 0)
-        TRY(pack_conv(u, co_, ci_, 5, 64, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b,
+        TRY(pack_conv(u, co_, ci_, 5, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b,
                       co_, [=](int k, int n) { return wr[(size_t)k * ci_ + n]; }));
       else
         first_wr = wr;
       TRY(upload_vec(u, br, co_, &b.br));
     } else if (bi > 0) {
-      TRY(pack_conv(u, co_, ci_, 5, 64, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b));
+      TRY(pack_conv(u, co_, ci_, 5, [=](int tap, int k, int n) { return w1[((size_t)k * ci_ + n) * 5 + (4 - tap)]; }, &b.c1b));
     }
     u->blocks.push_back(b);
   }
@@ -713,8 +661,8 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
     int c = cfg->dims[i];
     const float* w = cur.take((int64_t)c * c * 3);
     const float* b = cur.take(c);
-    TRY(pack_conv(u, c, c, 3, 32, [=](int tap, int ci, int co) { return w[((size_t)co * c + ci) * 3 + tap]; }, &u->down_f[i]));
-    TRY(pack_conv(u, c, c, 3, 64, [=](int tap, int k, int n) { return w[((size_t)k * c + n) * 3 + (2 - tap)]; }, &u->down_b[i]));
+    TRY(pack_conv(u, c, c, 3, [=](int tap, int ci, int co) { return w[((size_t)co * c + ci) * 3 + tap]; }, &u->down_f[i]));
+    TRY(pack_conv(u, c, c, 3, [=](int tap, int k, int n) { return w[((size_t)k * c + n) * 3 + (2 - tap)]; }, &u->down_b[i]));
     TRY(upload_vec(u, b, c, &u->down_bias[i]));
   }
   // up-sample convs (ConvTranspose1d k4 s2 p1), weight (in, out, 4); ups.0 is the deepest
@@ -722,8 +670,8 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
     int c = cfg->dims[1 - i];
     const float* w = cur.take((int64_t)c * c * 4);
     const float* b = cur.take(c);
-    TRY(pack_conv(u, c, c, 4, 64, [=](int tap, int ci, int co) { return w[((size_t)ci * c + co) * 4 + (3 - tap)]; }, &u->up_f[i]));
-    TRY(pack_conv(u, c, c, 4, 32, [=](int tap, int k, int n) { return w[((size_t)n * c + k) * 4 + tap]; }, &u->up_b[i]));
+    TRY(pack_conv(u, c, c, 4, [=](int tap, int ci, int co) { return w[((size_t)ci * c + co) * 4 + (3 - tap)]; }, &u->up_f[i]));
+    TRY(pack_conv(u, c, c, 4, [=](int tap, int k, int n) { return w[((size_t)n * c + k) * 4 + tap]; }, &u->up_b[i]));
     TRY(upload_vec(u, b, c, &u->up_bias[i]));
   }
   {
@@ -732,8 +680,8 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
     const float* b = cur.take(c);
     const float* g = cur.take(c);
     const float* be = cur.take(c);
-    TRY(pack_conv(u, c, c, 5, 64, [=](int tap, int ci, int co) { return w[((size_t)co * c + ci) * 5 + tap]; }, &u->final_f));
-    TRY(pack_conv(u, c, c, 5, 64, [=](int tap, int k, int n) { return w[((size_t)k * c + n) * 5 + (4 - tap)]; }, &u->final_b));
+    TRY(pack_conv(u, c, c, 5, [=](int tap, int ci, int co) { return w[((size_t)co * c + ci) * 5 + tap]; }, &u->final_f));
+    TRY(pack_conv(u, c, c, 5, [=](int tap, int k, int n) { return w[((size_t)k * c + n) * 5 + (4 - tap)]; }, &u->final_b));
     TRY(upload_vec(u, b, c, &u->fb));
     TRY(upload_vec(u, g, c, &u->fg));
     TRY(upload_vec(u, be, c, &u->fbe));
@@ -803,22 +751,17 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
   // ---- buffer plan -------------------------------------------------------------------
   const int H = cfg->horizon;
   const int d0 = cfg->dims[0], d1 = cfg->dims[1], d2 = cfg->dims[2];
-  // TRACE_BF3_PLANES=1: activations are ALSO kept as pre-split bf16 plane tensors and the convs stage them by
-  // LDS-DMA.  Measured and left off: 3283 against 3680 trajectories/s -- the split VALU
-  // work it removes is not what bounds the 256-channel layers (338 vs 337 us), while the 2.5x write traffic and the
-  // un-overlapped DMA latency cost the 64 / 128-channel and 1x1 layers 11 - 100 %.
-  const bool planes = getenv("TRACE_BF3_PLANES") && getenv("TRACE_BF3_PLANES")[0] == '1';
-  u->b_cat1 = u->new_buf(2 * d1 * (H / 2), false, planes);
-  u->b_cat2 = u->new_buf(2 * d2 * (H / 4), false, planes);
-  u->b_ds[0] = u->new_buf(d0 * (H / 2), false, planes);
-  u->b_ds[1] = u->new_buf(d1 * (H / 4), false, planes);
-  u->b_up1 = u->new_buf(d0 * H, false, planes);
+  u->b_cat1 = u->new_buf(2 * d1 * (H / 2), false);
+  u->b_cat2 = u->new_buf(2 * d2 * (H / 4), false);
+  u->b_ds[0] = u->new_buf(d0 * (H / 2), false);
+  u->b_ds[1] = u->new_buf(d1 * (H / 4), false);
+  u->b_up1 = u->new_buf(d0 * H, false);
   u->b_f = u->new_buf(d0 * H, false);
   u->b_yf = u->new_buf(d0 * H, true);
   u->b_sf = u->new_buf(16, true);
   for (auto& b : u->blocks) {
-    u->b_h1.push_back(u->new_buf(b.cout * b.L, false, planes));
-    u->b_out.push_back(u->new_buf(b.cout * b.L, false, planes));
+    u->b_h1.push_back(u->new_buf(b.cout * b.L, false));
+    u->b_out.push_back(u->new_buf(b.cout * b.L, false));
     u->b_res.push_back(b.has_res ? u->new_buf(b.cout * b.L, false) : -1);
     u->b_y1.push_back(u->new_buf(b.cout * b.L, true));
     u->b_y2.push_back(u->new_buf(b.cout * b.L, true));
@@ -828,26 +771,15 @@ extern "C" int trace_unet_create(const trace_unet_config* cfg, const float* para
   int gmax = d0 * H;
   if (d1 * (H / 2) > gmax) gmax = d1 * (H / 2);
   if (d2 * (H / 4) > gmax) gmax = d2 * (H / 4);
-  u->b_T1 = u->new_buf(gmax, true, planes);
-  u->b_T2 = u->new_buf(gmax, true, planes);
-  u->b_G0 = u->new_buf(gmax, true, planes);
-  u->b_G1 = u->new_buf(gmax, true, planes);
-  u->b_dcat1 = u->new_buf(2 * d1 * (H / 2), true, planes);
-  u->b_dcat2 = u->new_buf(2 * d2 * (H / 4), true, planes);
-  {
-    void* z = nullptr;
-    if (hipMalloc(&z, 256) != hipSuccess || hipMemset(z, 0, 256) != hipSuccess) {
-      set_error("trace_unet_create: cannot allocate the zero cell");
-      trace_unet_destroy(u);
-      return TRACE_EHIP;
-    }
-    u->allocs.push_back(z);
-    u->zero_cell = z;
-  }
-  bool side_ok = hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming) == hipSuccess;
-  for (int i = 0; i < 3 && side_ok; ++i)
-    side_ok = hipStreamCreateWithFlags(&u->side[i], hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&u->ev_join[i], hipEventDisableTiming) == hipSuccess;
+  u->b_T1 = u->new_buf(gmax, true);
+  u->b_T2 = u->new_buf(gmax, true);
+  u->b_G0 = u->new_buf(gmax, true);
+  u->b_G1 = u->new_buf(gmax, true);
+  u->b_dcat1 = u->new_buf(2 * d1 * (H / 2), true);
+  u->b_dcat2 = u->new_buf(2 * d2 * (H / 4), true);
+  const bool side_ok = hipEventCreateWithFlags(&u->ev_fork, hipEventDisableTiming) == hipSuccess &&
+                       hipStreamCreateWithFlags(&u->side, hipStreamNonBlocking) == hipSuccess &&
+                       hipEventCreateWithFlags(&u->ev_join, hipEventDisableTiming) == hipSuccess;
   if (!side_ok) {
     set_error("trace_unet_create: cannot create the side streams / events");
     trace_unet_destroy(u);
@@ -900,13 +832,11 @@ Layout make_layout(const trace_unet* u, int rows, int save) {
   return l;
 }
 
+constexpr int PAIR_MAX_ROWS = 2048;
 enum ConvKind { K_CONV5, K_CONV1, K_DOWN_F, K_UP_F, K_DOWN_B, K_UP_B };
-
-thread_local const void* t_zero_cell = nullptr;     // set by trace_unet_forward / _backward_input
 
 int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
   ConvArgs a = a_in;
-  a.zero_cell = t_zero_cell;
   if (!conv_scheme(-1)) {                    // bf16 x 3 everywhere, nothing recorded
     a.wh = nullptr;
     a.in_amax = a.in2_amax = nullptr;
@@ -914,88 +844,35 @@ int run_conv(ConvKind kind, int L_out, const ConvArgs& a_in, hipStream_t st) {
   }
   // zero-stuffed (transposed) convolutions multiply half of their taps by structural zeros
   if (kind == K_UP_F || kind == K_DOWN_B) a.alg_macs_per_pos *= 0.5;
-  const int ch = a.chunk;
-  // split-bf16 kernel wherever the layer has a packed stream for it (stride-1 and zero-stuffed
-  // convs with input channels in multiples of 32); TRACE_CONV_FP32=1 forces the fp32-MFMA kernel
-  static const bool force_fp32 = [] {
-    const char* e = getenv("TRACE_CONV_FP32");
-    return e && e[0] == '1';
-  }();
-  // diagnostic: TRACE_BF3_MASK = bit mask over (kind * 3 + level) of the layers allowed on the bf16 pipe
-  static const long bf3_mask = [] {
-    const char* e = getenv("TRACE_BF3_MASK");
-    return e ? strtol(e, nullptr, 0) : -1L;
-  }();
-  const int level = L_out == 52 ? 0 : L_out == 26 ? 1 : 2;
-  static const int f_cin = getenv("TRACE_BF3_CIN") ? atoi(getenv("TRACE_BF3_CIN")) : 0;
-  static const int f_cout = getenv("TRACE_BF3_COUT") ? atoi(getenv("TRACE_BF3_COUT")) : 0;
-  if (a.wb && !force_fp32 && ((bf3_mask >> ((int)kind * 3 + level)) & 1) && (!f_cin || f_cin == a.cin) &&
-      (!f_cout || f_cout == a.cout) && !(a.cin_b != a.cin && getenv("TRACE_BF3_NOFIRST"))) {
-    a.cin = a.cin_b;     // the first layer's 38 channels: 64 on this path (48 on the fp32 one), zero weights
-    switch (kind) {
-      case K_CONV5:
-        if (L_out == 52) return launch_conv_bf3<52, 1, 5, 2, 4>(a, st);
-        if (L_out == 26) return launch_conv_bf3<26, 1, 5, 2, 8>(a, st);
-        if (L_out == 13) return launch_conv_bf3<13, 1, 5, 2, 16>(a, st);
-        break;
-      case K_CONV1:
-        if (L_out == 52) return launch_conv_bf3<52, 1, 1, 0, 4>(a, st);
-        if (L_out == 26) return launch_conv_bf3<26, 1, 1, 0, 8>(a, st);
-        if (L_out == 13) return launch_conv_bf3<13, 1, 1, 0, 16>(a, st);
-        break;
-      case K_UP_F:
-        if (L_out == 26) return launch_conv_bf3<26, 2, 4, 2, 8>(a, st);
-        if (L_out == 52) return launch_conv_bf3<52, 2, 4, 2, 4>(a, st);
-        break;
-      case K_DOWN_B:
-        if (L_out == 52) return launch_conv_bf3<52, 2, 3, 1, 4>(a, st);
-        if (L_out == 26) return launch_conv_bf3<26, 2, 3, 1, 8>(a, st);
-        break;
-      case K_DOWN_F:      // Conv1d k3 s2 p1
-        if (getenv("TRACE_S2_FP32")) break;
-        if (L_out == 26) return launch_conv_bf3_s2<26, 3, 1, 8>(a, st);
-        if (L_out == 13) return launch_conv_bf3_s2<13, 3, 1, 16>(a, st);
-        break;
-      case K_UP_B:        // dgrad of ConvTranspose1d k4 s2 p1
-        if (getenv("TRACE_S2_FP32")) break;
-        if (L_out == 26) return launch_conv_bf3_s2<26, 4, 1, 8>(a, st);
-        if (L_out == 13) return launch_conv_bf3_s2<13, 4, 1, 16>(a, st);
-        break;
-      default:
-        break;
-    }
-  }
   switch (kind) {
     case K_CONV5:
-      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 1, 5, 2, 4, 64>(a, st);
-      if (L_out == 52 && ch == 48) return launch_conv<52, 1, 1, 5, 2, 4, 48>(a, st);
-      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 1, 5, 2, 8, 64>(a, st);
-      if (L_out == 13 && ch == 64) return launch_conv<13, 1, 1, 5, 2, 16, 64>(a, st);
+      if (L_out == 52) return launch_conv_bf3<52, 1, 5, 2, 4>(a, st);
+      if (L_out == 26) return launch_conv_bf3<26, 1, 5, 2, 8>(a, st);
+      if (L_out == 13) return launch_conv_bf3<13, 1, 5, 2, 16>(a, st);
       break;
     case K_CONV1:
-      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 1, 1, 0, 4, 64>(a, st);
-      if (L_out == 52 && ch == 48) return launch_conv<52, 1, 1, 1, 0, 4, 48>(a, st);
-      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 1, 1, 0, 8, 64>(a, st);
-      if (L_out == 13 && ch == 64) return launch_conv<13, 1, 1, 1, 0, 16, 64>(a, st);
-      break;
-    case K_DOWN_F:
-      if (L_out == 26 && ch == 32) return launch_conv<26, 2, 1, 3, 1, 8, 32>(a, st);
-      if (L_out == 13 && ch == 32) return launch_conv<13, 2, 1, 3, 1, 16, 32>(a, st);
+      if (L_out == 52) return launch_conv_bf3<52, 1, 1, 0, 4>(a, st);
+      if (L_out == 26) return launch_conv_bf3<26, 1, 1, 0, 8>(a, st);
+      if (L_out == 13) return launch_conv_bf3<13, 1, 1, 0, 16>(a, st);
       break;
     case K_UP_F:
-      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 2, 4, 2, 8, 64>(a, st);
-      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 2, 4, 2, 4, 64>(a, st);
+      if (L_out == 26) return launch_conv_bf3<26, 2, 4, 2, 8>(a, st);
+      if (L_out == 52) return launch_conv_bf3<52, 2, 4, 2, 4>(a, st);
       break;
     case K_DOWN_B:
-      if (L_out == 52 && ch == 64) return launch_conv<52, 1, 2, 3, 1, 4, 64>(a, st);
-      if (L_out == 26 && ch == 64) return launch_conv<26, 1, 2, 3, 1, 8, 64>(a, st);
+      if (L_out == 52) return launch_conv_bf3<52, 2, 3, 1, 4>(a, st);
+      if (L_out == 26) return launch_conv_bf3<26, 2, 3, 1, 8>(a, st);
       break;
-    case K_UP_B:
-      if (L_out == 13 && ch == 32) return launch_conv<13, 2, 1, 4, 1, 16, 32>(a, st);
-      if (L_out == 26 && ch == 32) return launch_conv<26, 2, 1, 4, 1, 8, 32>(a, st);
+    case K_DOWN_F:      // Conv1d k3 s2 p1
+      if (L_out == 26) return launch_conv_bf3_s2<26, 3, 1, 8>(a, st);
+      if (L_out == 13) return launch_conv_bf3_s2<13, 3, 1, 16>(a, st);
+      break;
+    case K_UP_B:        // dgrad of ConvTranspose1d k4 s2 p1
+      if (L_out == 26) return launch_conv_bf3_s2<26, 4, 1, 8>(a, st);
+      if (L_out == 13) return launch_conv_bf3_s2<13, 4, 1, 16>(a, st);
       break;
   }
-  set_error("no conv kernel for kind %d L_out %d chunk %d", (int)kind, L_out, ch);
+  set_error("no conv kernel for kind %d L_out %d", (int)kind, L_out);
   return TRACE_EINVAL;
 }
 
@@ -1004,11 +881,9 @@ struct View {
   int ctot;
   int coff;
   int L;
-  void* pl = nullptr;     // pre-split bf16 planes of the same (ctot, L) tensor, or null
   unsigned* amax = nullptr;   // max |value| per 16 trajectories, recorded by the tensor's producer(s), or null
   int tstride() const { return ctot * L; }
-  View sub(int c0) const { return View{p, ctot, coff + c0, L, pl, amax}; }
-  View no_planes() const { return View{p, ctot, coff, L, nullptr, amax}; }
+  View sub(int c0) const { return View{p, ctot, coff + c0, L, amax}; }
 };
 
 ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const View& out,
@@ -1018,9 +893,6 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.in_tstride = in.tstride();
   a.in_coff = in.coff;
   a.cin = w.cin;
-  a.chunk = w.chunk;
-  a.wp = w.w;
-  a.nkb = w.nkb;
   a.bias = bias;
   a.out = out.p;
   a.out_tstride = out.tstride();
@@ -1031,21 +903,10 @@ ConvArgs conv_args(const View& in, const PackedConv& w, const float* bias, const
   a.cin2 = w.cin2;     // the caller must point in2 at the second source (set_in2)
   a.wb = w.wb;
   a.nsl = w.nsl;
-  a.cin_b = w.cin_b;
   a.wh = w.wh;
   a.wexp = w.wexp;
   a.in_amax = in.amax;
   a.out_amax = out.amax;
-  if (in.pl && in.coff % 8 == 0 && in.ctot % 8 == 0) {
-    a.inp = in.pl;
-    a.inp_noct = in.ctot / 8;
-    a.inp_oct0 = in.coff / 8;
-  }
-  if (out.pl && out.coff % 8 == 0 && out.ctot % 8 == 0) {
-    a.outp = out.pl;
-    a.outp_noct = out.ctot / 8;
-    a.outp_oct0 = out.coff / 8;
-  }
   return a;
 }
 
@@ -1054,11 +915,6 @@ void set_in2(ConvArgs& a, const View& v) {
   a.in2_tstride = v.tstride();
   a.in2_coff = v.coff;
   a.in2_amax = v.amax;
-  if (v.pl && v.coff % 8 == 0 && v.ctot % 8 == 0) {
-    a.in2p = v.pl;
-    a.in2p_noct = v.ctot / 8;
-    a.in2p_oct0 = v.coff / 8;
-  }
 }
 
 // GroupNorm + Mish backward fused into a dgrad epilogue: `dy` receives d/dy of the layer whose
@@ -1073,17 +929,11 @@ void set_gnb(ConvArgs& a, const float* y, const float* stats, const float* gamma
   a.gb_beta = beta;
   a.gb_cg = C / 8;
   a.gb_c = C;
-  a.rawp = nullptr;
   if (raw) {
     a.out_raw = raw->p;
     a.raw_tstride = raw->tstride();
     a.raw_coff = raw->coff;
     a.raw_amax = raw->amax;
-    if (raw->pl && raw->coff % 8 == 0 && raw->ctot % 8 == 0) {
-      a.rawp = raw->pl;
-      a.rawp_noct = raw->ctot / 8;
-      a.rawp_oct0 = raw->coff / 8;
-    }
   } else {
     a.out_raw = nullptr;
     a.raw_amax = nullptr;
@@ -1092,12 +942,6 @@ void set_gnb(ConvArgs& a, const float* y, const float* stats, const float* gamma
   a.out = dy.p;
   a.out_tstride = dy.tstride();
   a.out_coff = dy.coff;
-  a.outp = nullptr;
-  if (dy.pl && dy.coff % 8 == 0 && dy.ctot % 8 == 0) {
-    a.outp = dy.pl;
-    a.outp_noct = dy.ctot / 8;
-    a.outp_oct0 = dy.coff / 8;
-  }
 }
 
 void set_res(ConvArgs& a, const View& r) {
@@ -1133,38 +977,35 @@ int run_gn_bwd(const View& da, const float* y, const float* stats, const float* 
 }  // namespace
 
 // Large calls run as two halves of their rows on two streams (the caller's and the model's side stream, fork / join
-// by events; calls under stream capture stay on one stream): every kernel boundary drains the chip, and with two independent launch
-// sequences one half's ramp-down overlaps the other's ramp-up, as do the small kernels.  Same kernels per row, so
-// the same bits.  Measured: 10.42 -> 10.09 ms per pass at 10240 rows (scripts/exp_two_streams.py).  `quantum` = row
-// granularity of the cut (amax groups of 16, cond-table rows).  TRACE_UNET_SPLIT_MIN = smallest call that is split
-// (default 4096 rows, 0 = never).  Not used while per-launch profiling events are being recorded.
-// One call at a time per model (the side stream and the events belong to the model).
+// by events; calls under stream capture stay on one stream): every kernel boundary drains the chip, and with two
+// independent launch sequences one half's ramp-down overlaps the other's ramp-up, as do the small kernels.  Same
+// kernels per row, so the same bits.  Measured: 10.42 -> 10.09 ms per pass at 10240 rows (scripts/exp_two_streams.py;
+// three or four parts measured the same as two).  `quantum` = row granularity of the cut (amax groups of 16,
+// cond-table rows).  Not used while per-launch profiling events are being recorded.  The side stream and the events
+// belong to the model: a call that finds them in use (another thread driving the same model) runs unsplit.
+constexpr int SPLIT_MIN_ROWS = 4096;
 template <typename F>
 int run_split(trace_unet* u, int rows, int quantum, hipStream_t st, F&& part) {
-  static const int split_min = getenv("TRACE_UNET_SPLIT_MIN") ? atoi(getenv("TRACE_UNET_SPLIT_MIN")) : 4096;
-  static const int nparts_env = getenv("TRACE_UNET_SPLIT_PARTS") ? atoi(getenv("TRACE_UNET_SPLIT_PARTS")) : 2;
-  const int nparts = nparts_env < 2 ? 2 : (nparts_env > 4 ? 4 : nparts_env);
-  const int per = quantum > 0 ? (rows / nparts / quantum) * quantum : 0;
-  if (split_min <= 0 || rows < split_min || per <= 0 || prof_active() || prof_stamping() || !u->side[0])
-    return part(0, rows, st);
+  const int per = quantum > 0 ? (rows / 2 / quantum) * quantum : 0;
+  if (rows < SPLIT_MIN_ROWS || per <= 0 || prof_active() || prof_stamping() || !u->side) return part(0, rows, st);
   // not under stream capture: a replayed graph ran its two branches slower than one (4435 against 4730 trajectories/s)
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return part(0, rows, st);
-  TRACE_CHECK_HIP(hipEventRecord(u->ev_fork, st));
-  for (int i = 0; i + 1 < nparts; ++i) TRACE_CHECK_HIP(hipStreamWaitEvent(u->side[i], u->ev_fork, 0));
-  int rc = part(0, per, st);
-  for (int i = 1; i < nparts; ++i) {
-    const int r0 = i * per;
-    const int rc2 = part(r0, i + 1 == nparts ? rows - r0 : per, u->side[i - 1]);
+  if (__atomic_exchange_n(&u->busy, 1, __ATOMIC_ACQUIRE)) return part(0, rows, st);
+  int rc = TRACE_OK;
+  if (hipEventRecord(u->ev_fork, st) != hipSuccess || hipStreamWaitEvent(u->side, u->ev_fork, 0) != hipSuccess) {
+    set_error("run_split: fork failed");
+    rc = TRACE_EHIP;
+  } else {
+    rc = part(0, per, st);
+    const int rc2 = part(per, rows - per, u->side);
     if (!rc) rc = rc2;
-  }
-  // join even after an error, so that no stream is left running behind the caller's back
-  for (int i = 0; i + 1 < nparts; ++i) {
-    if (hipEventRecord(u->ev_join[i], u->side[i]) != hipSuccess ||
-        hipStreamWaitEvent(st, u->ev_join[i], 0) != hipSuccess) {
+    // join even after an error, so that no stream is left running behind the caller's back
+    if (hipEventRecord(u->ev_join, u->side) != hipSuccess || hipStreamWaitEvent(st, u->ev_join, 0) != hipSuccess) {
       if (!rc) { set_error("run_split: join failed"); rc = TRACE_EHIP; }
     }
   }
+  __atomic_store_n(&u->busy, 0, __ATOMIC_RELEASE);
   return rc;
 }
 
@@ -1211,8 +1052,6 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
   const float* pt = u->step_table + (size_t)step * u->width;
 
   // views of each block's input / output (skip concatenation is done by writing in place)
-  t_zero_cell = u->zero_cell;
-  // a buffer with its plane twin (the twin is written by the producing conv's epilogue)
   TRACE_REQUIRE((int)u->buf_floats.size() <= AMAX_SLOTS, "amax slots: %d buffers", (int)u->buf_floats.size());
   unsigned* const amax_all = reinterpret_cast<unsigned*>(ws + lay.amax_off);
   TRACE_CHECK_HIP(hipMemsetAsync(amax_all, 0, (size_t)AMAX_SLOTS * lay.ngroups * sizeof(unsigned), st_all));
@@ -1226,15 +1065,13 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
     return id >= 0 && lay.off[id] >= 0 ? ws + lay.off[id] + (size_t)r0 * u->buf_floats[id] : nullptr;
   };
   auto whole = [&](int id, int C, int L) {
-    const int tw = id >= 0 ? u->buf_twin[id] : -1;
-    return View{buf(id), C, 0, L, tw >= 0 ? (void*)buf(tw) : nullptr,
-                id >= 0 ? amax_base + (size_t)id * lay.ngroups : nullptr};
+    return View{buf(id), C, 0, L, id >= 0 ? amax_base + (size_t)id * lay.ngroups : nullptr};
   };
   std::vector<View> bin(u->nblocks), bout(u->nblocks);
   const int d0 = c.dims[0], d1 = c.dims[1], d2 = c.dims[2];
   View cat1 = whole(u->b_cat1, 2 * d1, H / 2), cat2 = whole(u->b_cat2, 2 * d2, H / 4);
   // block order: d0.0 d0.1 d1.0 d1.1 d2.0 d2.1 mid1 mid2 u0.0 u0.1 u1.0 u1.1
-  bin[0] = View{const_cast<float*>(x_in), u->cin_pad, 0, H};
+  bin[0] = View{const_cast<float*>(x_in), u->cin_pad, 0, H, nullptr};
   for (int i = 0; i < u->nblocks; ++i) bout[i] = whole(u->b_out[i], u->blocks[i].cout, u->blocks[i].L);
   bout[3] = cat1.sub(d1);   // d1.1 -> skip half of cat1
   bout[5] = cat2.sub(d2);   // d2.1 -> skip half of cat2
@@ -1264,22 +1101,13 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
     if (b.has_res) {
       r = whole(u->b_res[i], b.cout, b.L);
       ConvArgs ar = conv_args(bin[i], b.rf, b.br, r, rows);
-      // the k5 conv and the 1x1 residual conv of the block in one launch (fp16 scheme, full-chip launches)
-      // Measured (A/B inside one call).  Full-chip launches: 10.46 ms per pass paired against 10.39 separate -- no
-      // gain, the 1x1 workgroups only trade places with k5 workgroups on the same issue-bound CUs.  Small launches
-      // (cfg1, 320 rows, one workgroup per CU at most): 79.9 ms per 100-step call against 87.5 -- four launches
-      // less per step on a latency-bound chain.  Default: small launches only (TRACE_CONV_PAIR = 0 none, 1 large,
-      // 2 small, 3 all).
-      static const int pair_mode = getenv("TRACE_CONV_PAIR") ? atoi(getenv("TRACE_CONV_PAIR")) : 2;
-      const bool small = rows < 2048;
-      if ((pair_mode & (small ? 2 : 1)) && conv_scheme(-1) && a.wh && ar.wh && a.in_amax && a.cin_b == a.cin &&
-          a.cin % 64 == 0 && !prof_stamping()) {
-        ConvArgs a1 = a, a2 = ar;
-        a1.cin = a1.cin_b; a2.cin = a2.cin_b;
-        a1.zero_cell = a2.zero_cell = t_zero_cell;
-        if (b.L == 52) RUN((launch_conv_pair<52, 4>(a1, a2, st)));
-        else if (b.L == 26) RUN((launch_conv_pair<26, 8>(a1, a2, st)));
-        else RUN((launch_conv_pair<13, 16>(a1, a2, st)));
+      // Small launches (at most one workgroup per CU: cfg1's 320 rows) run the k5 conv and the 1x1 residual conv of
+      // the block as one launch, side by side on different CUs instead of back to back: 87.5 -> 79.9 ms per 100-step
+      // call.  Full-chip launches gain nothing from it (10.46 ms per pass paired against 10.39) and stay separate.
+      if (rows < PAIR_MAX_ROWS && conv_scheme(-1) && a.wh && ar.wh && a.in_amax && a.cin % 64 == 0 && !prof_stamping()) {
+        if (b.L == 52) RUN((launch_conv_pair<52, 4>(a, ar, st)));
+        else if (b.L == 26) RUN((launch_conv_pair<26, 8>(a, ar, st)));
+        else RUN((launch_conv_pair<13, 16>(a, ar, st)));
         paired = true;
       }
       if (!paired) RUN(run_conv(K_CONV1, b.L, ar, st));
@@ -1288,22 +1116,6 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
     a2.gn = 1; a2.cg = b.cout / 8; a2.gamma = b.g2; a2.beta = b.be2;
     set_res(a2, r);
     if (save) { a2.ysave = buf(u->b_y2[i]); a2.stats = buf(u->b_s2[i]); }
-    // blocks of 64 output channels (= one workgroup tile; L = 52 and the last two of L = 26): both k5 convs in one launch, the activation between
-    // them stays in LDS (conv_block_fwd_kernel).  Measured: the fused launch takes 249 us against 2 x 142 us, yet a
-    // pass does not get faster (10.06 against 10.00 ms, A/B inside one call; 256 VGPRs + 108 B of scratch): opt-in,
-    // TRACE_BLOCK_FUSE=1
-    static const int block_mode = getenv("TRACE_BLOCK_FUSE") ? atoi(getenv("TRACE_BLOCK_FUSE")) : 0;  // 1: large, 2: small, 3: all
-    if (!paired && (block_mode & (rows < 2048 ? 2 : 1)) && (b.L == 52 || b.L == 26) && b.cout == 64 && conv_scheme(-1) &&
-        a.wh && a2.wh && a.in_amax && a.cin_b == a.cin && a.cin % 64 == 0 && !prof_stamping() && !force_fp32_convs()) {
-      ConvArgs a1 = a;
-      a1.cin = a1.cin_b; a2.cin = a2.cin_b;
-      a1.zero_cell = a2.zero_cell = t_zero_cell;
-      a1.out = nullptr; a1.out_amax = nullptr; a1.keep_tile = 1;
-      a2.in_amax = nullptr;                       // conv 2 scales by its own tile's maximum
-      if (b.L == 52) RUN((launch_conv_block_fwd<52, 4>(a1, a2, st)));
-      else RUN((launch_conv_block_fwd<26, 8>(a1, a2, st)));
-      return TRACE_OK;
-    }
     if (!paired) RUN(run_conv(K_CONV5, b.L, a, st));
     RUN(run_conv(K_CONV5, b.L, a2, st));
     return TRACE_OK;
@@ -1334,8 +1146,7 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
     if (save) { a.ysave = buf(u->b_yf); a.stats = buf(u->b_sf); }
     // the 1x1 head rides in this conv's epilogue (the whole 64-channel activation of a trajectory is in the
     // workgroup's tile) and the activation itself, which nothing else reads, is not written
-    static const bool no_fuse = getenv("TRACE_NO_HEAD_FUSE") != nullptr;
-    head_fused = !no_fuse && d0 == 64 && a.wb && !force_fp32_convs();
+    head_fused = d0 == 64;
     if (head_fused) {
       a.head_w = u->head_w; a.head_b = u->head_b; a.head_pred = pred;
       a.out = nullptr; a.out_amax = nullptr;
@@ -1371,8 +1182,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred_a
   const trace_unet_config& c = u->cfg;
   const int H = c.horizon;
   const int d0 = c.dims[0], d1 = c.dims[1], d2 = c.dims[2];
-  t_zero_cell = u->zero_cell;
-  // views of the gradient scratch buffers with their plane twins; the same buffer is reused with different
+  // views of the gradient scratch buffers; the same buffer is reused with different
   // (channels, length) shapes, which is consistent as long as a tensor's producer and consumers agree
   // amax slots: the gradient buffers are rewritten many times with different tensors, so every PRODUCED tensor
   // takes a fresh slot (`produced`), and later views of the buffer carry the slot of its latest producer
@@ -1387,9 +1197,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred_a
   std::vector<int> slot_of(u->buf_floats.size(), -1);
   int next_slot = 0;
   auto view = [&](int id, int C, int coff, int L) {
-    const int tw = u->buf_twin[id];
-    return View{buf(id), C, coff, L, tw >= 0 ? (void*)buf(tw) : nullptr,
-                slot_of[id] >= 0 ? amax_base + (size_t)slot_of[id] * lay.ngroups : nullptr};
+    return View{buf(id), C, coff, L, slot_of[id] >= 0 ? amax_base + (size_t)slot_of[id] * lay.ngroups : nullptr};
   };
   auto produced = [&](int id, int C, int coff, int L) {
     slot_of[id] = next_slot < AMAX_SLOTS ? next_slot++ : -1;       // out of slots: consumers fall back to bf16 x 3
@@ -1439,7 +1247,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred_a
   // head + final block
   {
     View g0 = view(iG0, d0, 0, H), g1 = produced(iG1, d0, 0, H);
-    View t1 = view(iT1, d0, 0, H).no_planes();          // written by gn_mish_bwd_kernel: fp32 only, no amax
+    View t1 = view(iT1, d0, 0, H);                      // written by gn_mish_bwd_kernel: no amax
     RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, t1.p, d0, H, rows, st, grad_pred, u->head_w, gscale));
     RUN(run_conv(K_CONV5, H, conv_args(t1, u->final_b, nullptr, g1, rows), st));
   }
@@ -1489,7 +1297,7 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred_a
   // first block: only input channels [4,5] are needed (tbsim/models/trace.py:674-676)
   {
     const Block& b = u->blocks[0];
-    View t1 = view(iT1, d0, 0, H), t2 = produced(iT2, d0, 0, H).no_planes();      // t2 feeds first_dgrad_kernel (fp32)
+    View t1 = view(iT1, d0, 0, H), t2 = produced(iT2, d0, 0, H);      // t2 feeds first_dgrad_kernel
     ConvArgs a = conv_args(t1, b.c2b, nullptr, t2, rows);
     set_gnb(a, buf(u->b_y1[0]), buf(u->b_s1[0]), b.g1, b.be1, b.cout, t2, nullptr);
     RUN(run_conv(K_CONV5, b.L, a, st));
