@@ -39,14 +39,18 @@ void prof_post(hipStream_t st, double flops, double pipe_seconds);
 constexpr double PEAK_MFMA16_FLOPS = 2500e12;    // dense bf16 / fp16 MFMA (MI355X_MICROARCH.md)
 constexpr double PEAK_MFMA32_FLOPS = 157.3e12;   // fp32 MFMA
 
-// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to a (kernel, device) pair: `done` is one bit
-// per device ordinal, owned by the launcher of one kernel instantiation.  Returns true when the attribute
-// still has to be set for the CURRENT device (and records it); thread-safe.
-inline bool first_launch_on_device(unsigned long long* done) {
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) belongs to a (kernel, device) pair: `done` is one bit per device
+// ordinal, owned by the launcher of one kernel instantiation.  The bit is set only AFTER the attribute call has
+// succeeded, so a second host thread can never launch with more than 64 KB of LDS ahead of it (two threads that race
+// both make the call, which is harmless).  Returns a HIP error code.
+inline hipError_t ensure_dynamic_lds(unsigned long long* done, const void* func, int bytes) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-  const unsigned long long bit = 1ull << dev;
-  return (__atomic_fetch_or(done, bit, __ATOMIC_ACQ_REL) & bit) == 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev <= 63;
+  const unsigned long long bit = known ? 1ull << dev : 0ull;
+  if (known && (__atomic_load_n(done, __ATOMIC_ACQUIRE) & bit)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && known) __atomic_fetch_or(done, bit, __ATOMIC_ACQ_REL);
+  return e;
 }
 
 inline int launch_status(const char* what) {
@@ -124,8 +128,9 @@ __device__ __forceinline__ float mish_grad_fast_f(float x) {
   q = __builtin_fmaf(__builtin_fmaf(-e1, q, 1.f), q, q);
   float tsp = n * r;
   float sig = e * q;
-  // x > 20: with the clamped exponent the second term is below 2^-24 and tsp is 1 to within an ulp
-  return tsp + x * sig * (4.f * (n + 1.f) * (r * r));
+  // x > 20: tsp is 1 to within an ulp and, with x clamped here too, the second term stays below 2^-24 for every x
+  // up to +inf (the reference returns exactly 1 there)
+  return tsp + xc * sig * (4.f * (n + 1.f) * (r * r));
 }
 
 }  // namespace trace

@@ -223,10 +223,8 @@ int launch_conv2d(const Conv2dArgs& a_in, hipStream_t st) {
   Conv2dArgs a = a_in;
   a.tiles_per_image = (a.Ho + TR - 1) / TR;
   static unsigned long long attr_done = 0;
-  if (first_launch_on_device(&attr_done)) {
-    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv2d_bf3_kernel<KH, KW, S, PAD, TR, WO>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-  }
+  TRACE_CHECK_HIP(ensure_dynamic_lds(&attr_done, reinterpret_cast<const void*>(&conv2d_bf3_kernel<KH, KW, S, PAD, TR, WO>),
+                                     80 * 1024));
   const long wgs = (long)a.B * a.tiles_per_image * ((a.cout + 63) / 64);
   TRACE_REQUIRE(wgs > 0 && wgs < 0x7fffffffL, "conv2d: grid of %ld workgroups", wgs);
   hipLaunchKernelGGL((conv2d_bf3_kernel<KH, KW, S, PAD, TR, WO>), dim3((unsigned)wgs), dim3(256), G::LDS_BYTES, st, a);
@@ -428,9 +426,7 @@ extern "C" int trace_map_stem(const float* image, const float* w_tap_ci_co, cons
   TRACE_REQUIRE(Ho <= 65535 && B <= 65535, "trace_map_stem: grid too large (B = %d)", B);
   const size_t smem = (size_t)(49 * C * 64 + C * 7 * 37) * sizeof(float);
   static unsigned long long attr_done = 0;
-  if (first_launch_on_device(&attr_done))
-    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&stem7x7_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+  TRACE_CHECK_HIP(ensure_dynamic_lds(&attr_done, reinterpret_cast<const void*>(&stem7x7_kernel), 120 * 1024));
   hipLaunchKernelGGL(stem7x7_kernel, dim3((Wo + 15) / 16, Ho, B), dim3(256), smem, (hipStream_t)stream, image,
                      w_tap_ci_co, scale, shift, out, C, H, W, Ho, Wo);
   return launch_status("stem7x7_kernel");

@@ -188,8 +188,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
       // units past NU (last pass) read a valid address and are never written to LDS; trajectories
       // past `rows` fall outside the descriptor's range and read as zeros
       const bool live = (NU % NTH == 0) || (tid + NTH * j < NU);
+      const unsigned sp = spk[j];
       const unsigned off = none ? 0xffffe000u
-                                : (live ? ((spk[j] >> 20) * (unsigned)tstride + (spk[j] & 0xfffffu) + (unsigned)cbase) * 4u : 0u);
+                                : (live ? ((sp >> 20) * (unsigned)tstride + (sp & 0xfffffu) + (unsigned)cbase) * 4u : 0u);
 #pragma unroll
       for (int jj = 0; jj < 8; ++jj) {
         stg[j][jj] = second ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc2, off, jj * L_IN * 4, 0))
@@ -519,10 +520,7 @@ int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
   constexpr size_t lds_bytes = la > lb ? la : lb;
   static_assert(lds_bytes <= 80 * 1024, "conv pair: LDS per workgroup too large for two per CU");
   static unsigned long long attr_done = 0;
-  if (first_launch_on_device(&attr_done)) {
-    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<L_OUT, TB, CHN>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-  }
+  TRACE_CHECK_HIP(ensure_dynamic_lds(&attr_done, reinterpret_cast<const void*>(&conv_pair_kernel<L_OUT, TB, CHN>), 100 * 1024));
   const int nrb = (a.rows + TB - 1) / TB;
   dim3 grid(((nrb + 7) / 8) * 8 * ((a.cout + b.cout) / 64));
   const bool prof = prof_active();
@@ -579,11 +577,9 @@ int launch_conv_bf3_impl(const ConvArgs& a_in, hipStream_t st) {
   static_assert(LDS_NEED <= (IS == 2 && SCH == 0 ? 100 : 80) * 1024, "conv(bf16x3): LDS per workgroup too large");
   constexpr size_t lds_bytes = LDS_NEED;
   static unsigned long long attr_done = 0;      // one bit per device
-  if (first_launch_on_device(&attr_done)) {
-    TRACE_CHECK_HIP(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, SCH, NW, MINW, CHN, IS, WPF>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
-  }
+  TRACE_CHECK_HIP(ensure_dynamic_lds(
+      &attr_done, reinterpret_cast<const void*>(&conv_bf3_kernel<L_OUT, UP, TAPS, PADL, TB, SCH, NW, MINW, CHN, IS, WPF>),
+      100 * 1024));
   const int nrb = (a.rows + TB - 1) / TB;
   dim3 grid(((nrb + 7) / 8) * 8 * (a.cout / 64));
 #ifdef TRACE_CONV_STAMPS
@@ -622,7 +618,10 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
   constexpr int MW = TRACE_BF3_WGS * TRACE_BF3_NW / 4;
   const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
   if (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax)) {          // every operand has its scale: the fp16 pipe
-    if constexpr (TAPS > 1) {
+#ifndef TRACE_F16_CH
+#define TRACE_F16_CH 64           // channels per chunk of the fp16 launches with more than one tap (32 / 64; build switch)
+#endif
+    if constexpr (TAPS > 1 && TRACE_F16_CH == 64) {
       if (a.cin % 64 == 0 && a.cin2 % 64 == 0)
         return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 64>(a, st);
     }

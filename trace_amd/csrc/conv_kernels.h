@@ -40,6 +40,7 @@ struct ConvArgs {
   int pc_stride;
   int pc_off;
   int rows_per_cond;
+  unsigned pc_magic;   // 2^32 / rows_per_cond + 1 (0 when rows_per_cond == 1): cond row by multiply-high
   const float* pt;     // per-step additive vector [cout] (already offset) or null
   const float* res;    // residual [rows][res_ctot][L_OUT] or null
   int res_tstride;
@@ -278,16 +279,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
   const int cwave = wave & 3;                        // column tile of the wave
   const bool has_tab = a.gn || a.pc;
   auto flat_live = [&](int k) -> bool { return !QTAIL || (tid + NTH * k) < NF4; };
-  auto flat_off = [&](int k, int tstride, int coff, int& rem_out) -> unsigned {
-    const int f = (tid + NTH * k) * 4;
-    const int tr = f / TILE;
-    const int rem = f - tr * TILE;
-    rem_out = rem;
-    const int tg = traj0 + tr;
-    // unsigned 32-bit byte offset: the launcher guarantees rows * tstride * 4 < 4 GiB; cells past the tile
-    // (partial last pass) and trajectories past `rows` fall outside every descriptor's range
-    return (tg < a.rows && flat_live(k)) ? ((unsigned)tg * (unsigned)tstride + (unsigned)((coff + co0) * L_OUT + rem)) * 4u
-                                         : 0xffffffffu;
+  // Flat cell tid + NTH k of the tile = trajectory ftg[k] (global index; -1: past `rows` or past the tile), float
+  // offset frem[k] inside that trajectory's 64-channel slab.  One division by a constant per thread, the passes
+  // differ by compile-time carries; every flat pass (residuals, saved output, raw gradient, output) shares them.
+  constexpr int CPT = TILE / 4;                      // 16-byte cells per trajectory
+  int ftg[NQ], frem[NQ];
+  {
+    const int q0 = tid / CPT, r0 = tid - q0 * CPT;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+      const int A = (NTH * k) / CPT, B = (NTH * k) % CPT;
+      int r = r0 + B, t = q0 + A;
+      if (r >= CPT) { r -= CPT; ++t; }
+      const int tg = traj0 + t;
+      ftg[k] = (tg < a.rows && flat_live(k)) ? tg : -1;
+      frem[k] = r * 4;
+    }
+  }
+  // unsigned 32-bit byte offset: the launcher guarantees rows * tstride * 4 < 4 GiB (so the 24-bit multiply is
+  // exact: rows, tstride < 2^24); invalid cells fall outside every descriptor's range
+  auto flat_off = [&](int k, int tstride, int coff) -> unsigned {
+    const unsigned o = (__umul24((unsigned)ftg[k], (unsigned)tstride) + (unsigned)((coff + co0) * L_OUT + frem[k])) * 4u;
+    return ftg[k] >= 0 ? o : 0xffffffffu;
   };
   auto lds_cell = [&](int k) -> float* { return lds + (flat_live(k) ? (tid + NTH * k) * 4 : 0); };
   f32x4 rv[NQ];
@@ -295,11 +308,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.res), 0, (unsigned)((size_t)a.rows * a.res_tstride * sizeof(float)), 0x00020000);
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      int rem;
+    for (int k = 0; k < NQ; ++k)
       rv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rr, flat_off(k, a.res_tstride, a.res_coff, rem), 0, 0));
-    }
+                                            rr, flat_off(k, a.res_tstride, a.res_coff), 0, 0));
   } else {
 #pragma unroll
     for (int k = 0; k < NQ; ++k) rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -309,9 +320,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
         const_cast<float*>(a.res2), 0, (unsigned)((size_t)a.rows * a.res2_tstride * sizeof(float)), 0x00020000);
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
-      int rem;
       f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                              rr, flat_off(k, a.res2_tstride, a.res2_coff, rem), 0, 0));
+                                              rr, flat_off(k, a.res2_tstride, a.res2_coff), 0, 0));
       rv[k] += t;
     }
   }
@@ -372,21 +382,28 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         a.out_raw ? a.out_raw : a.out, 0,
         a.out_raw ? (unsigned)((size_t)a.rows * a.raw_tstride * sizeof(float)) : 0u, 0x00020000);
-    float mraw = 0.f;
+    if (a.out_raw) {                           // uniform; two loops so that neither carries a branch per cell
+      float mraw = 0.f;
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) {
-      float* cell = lds_cell(k);
-      f32x4 y = *reinterpret_cast<const f32x4*>(cell);
-      y += rv[k];
-      if (a.out_raw) {
-        int rem;
-        const unsigned oo = flat_off(k, a.raw_tstride, a.raw_coff, rem);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rw, oo, 0, 0);
+      for (int k = 0; k < NQ; ++k) {
+        float* cell = lds_cell(k);
+        f32x4 y = *reinterpret_cast<const f32x4*>(cell);
+        y += rv[k];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), rw,
+                                               flat_off(k, a.raw_tstride, a.raw_coff), 0, 0);
         mraw = amax4(mraw, y);       // cells past the tile repeat cell 0, rows past `rows` hold the conv of zeros
+        if (flat_live(k)) *reinterpret_cast<f32x4*>(cell) = y;
       }
-      if (flat_live(k)) *reinterpret_cast<f32x4*>(cell) = y;
+      if (a.raw_amax) record_amax(a.raw_amax, traj0, mraw);
+    } else {
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) {
+        float* cell = lds_cell(k);
+        f32x4 y = *reinterpret_cast<const f32x4*>(cell);
+        y += rv[k];
+        if (flat_live(k)) *reinterpret_cast<f32x4*>(cell) = y;
+      }
     }
-    if (a.raw_amax && a.out_raw) record_amax(a.raw_amax, traj0, mraw);
     if (!normed) {                             // uniform per workgroup
       TRACE_STAMP(11);
       return;
@@ -475,9 +492,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       const f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
-      int rem;
-      const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro,
+                                             flat_off(k, a.out_tstride, a.out_coff), 0, 0);
       mout = amax4(mout, y);
     }
     if (a.out_amax) record_amax(a.out_amax, traj0, mout);
@@ -493,9 +509,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
 #pragma unroll
     for (int k = 0; k < NQ; ++k) {
       const f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
-      int rem2;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ry,
-                                             flat_off(k, a.cout * L_OUT, 0, rem2), 0, 0);
+                                             flat_off(k, a.cout * L_OUT, 0), 0, 0);
     }
     if (has_tab) __syncthreads();          // every flat read done before rows are rewritten
   }
@@ -517,7 +532,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int tg = min(traj0 + wave + NW * j, a.rows - 1);
-      add[j] = a.pc ? a.pc[(size_t)(tg / a.rows_per_cond) * a.pc_stride + a.pc_off + co] + ptv : 0.f;
+      // cond row = tg / rows_per_cond by multiply-high (pc_magic = 2^32 / rows_per_cond + 1, exact below 2^24 rows;
+      // 0 = one row per trajectory)
+      const unsigned cr = a.pc_magic ? __umulhi((unsigned)tg, a.pc_magic) : (unsigned)tg;
+      add[j] = a.pc ? a.pc[(size_t)cr * a.pc_stride + a.pc_off + co] + ptv : 0.f;
       rmean[j] = 0.f;
       m2[j] = 0.f;
       const float* row = lds + ((wave + NW * j) * 64 + c) * L_OUT;
@@ -594,15 +612,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
       for (int j = 0; j < NP; ++j) { scale[j] = 1.f; shift[j] = 0.f; }
     }
     TRACE_STAMP(8);
+    // (uniform condition hoisted: a branch per element kept the Mish chains of a row from overlapping)
+    if (a.gn) {
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) v[j][i] = mish_fast_f(fmaf(v[j][i], scale[j], shift[j])) + add[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < NP; ++j)
+#pragma unroll
+        for (int i = 0; i < L_OUT; ++i) v[j][i] = fmaf(v[j][i], scale[j], shift[j]) + add[j];
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       float* row = lds + ((wave + NW * j) * 64 + c) * L_OUT;
-#pragma unroll
-      for (int i = 0; i < L_OUT; ++i) {
-        float z = fmaf(v[j][i], scale[j], shift[j]);
-        if (a.gn) z = mish_fast_f(z);
-        v[j][i] = z + add[j];
-      }
       if constexpr (L_OUT % 4 == 0) {
 #pragma unroll
         for (int i = 0; i < L_OUT / 4; ++i)
@@ -644,10 +668,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
 #pragma unroll
   for (int k = 0; k < NQ; ++k) {
     f32x4 y = *reinterpret_cast<const f32x4*>(lds_cell(k));
-    int rem;
-    const unsigned oo = flat_off(k, a.out_tstride, a.out_coff, rem);
     y += rv[k];
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, oo, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, y), ro, flat_off(k, a.out_tstride, a.out_coff), 0, 0);
     mout = amax4(mout, y);
   }
   if (a.out_amax) record_amax(a.out_amax, traj0, mout);

@@ -705,12 +705,11 @@ int launch_conv_ws(const ConvArgs& a_in, hipStream_t st) {
                 "(%d rows)", a.rows);
   TRACE_REQUIRE(!a.pc || a.pt, "conv: cond table without step table");
   static unsigned long long attr_done = 0;      // one bit per device
-  if (first_launch_on_device(&attr_done)) {
-    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<L_OUT, UP, TAPS, PADL, TB, false>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES));
-    TRACE_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ws_kernel<L_OUT, UP, TAPS, PADL, TB, true>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)W::LDS_BYTES));
-  }
+  static unsigned long long attr_done_gnb = 0;
+  TRACE_CHECK_HIP(ensure_dynamic_lds(&attr_done, reinterpret_cast<const void*>(&conv_ws_kernel<L_OUT, UP, TAPS, PADL, TB, false>),
+                                     (int)W::LDS_BYTES));
+  TRACE_CHECK_HIP(ensure_dynamic_lds(&attr_done_gnb, reinterpret_cast<const void*>(&conv_ws_kernel<L_OUT, UP, TAPS, PADL, TB, true>),
+                                     (int)W::LDS_BYTES));
   const int ncol = a.cout / 64;
   const int nrb = (a.rows + TB - 1) / TB;
   const int ntv = ((nrb + 7) / 8) * 8 * ncol;            // virtual tile ids (the last group of 8 row blocks may be ragged)

@@ -1038,6 +1038,8 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
   TRACE_REQUIRE(rows >= 0 && rows_per_cond > 0, "trace_unet_forward: rows=%d rows_per_cond=%d", rows,
                 rows_per_cond);
   TRACE_REQUIRE(step >= 0 && step < u->cfg.n_steps, "step %d out of range", step);
+  TRACE_REQUIRE((uint64_t)rows * (uint64_t)rows_per_cond < (1ull << 32),
+                "trace_unet_forward: rows * rows_per_cond = %d * %d exceeds 2^32", rows, rows_per_cond);
   if (rows == 0) return TRACE_OK;
   Layout lay = make_layout(u, rows, save);
   if (lay.total * (int64_t)sizeof(float) > workspace_bytes) {
@@ -1094,6 +1096,7 @@ extern "C" int trace_unet_forward(trace_unet* u, const float* x_in_all, const fl
     ConvArgs a = conv_args(bin[i], b.c1f, b.b1, h1, rows);
     a.gn = 1; a.cg = b.cout / 8; a.gamma = b.g1; a.beta = b.be1;
     a.pc = cond_table; a.pc_stride = u->width; a.pc_off = b.emb_off; a.rows_per_cond = rows_per_cond;
+    a.pc_magic = rows_per_cond > 1 ? (unsigned)((1ull << 32) / (unsigned)rows_per_cond + 1) : 0u;
     a.pt = pt + b.emb_off;
     if (save) { a.ysave = buf(u->b_y1[i]); a.stats = buf(u->b_s1[i]); }
     View r = bin[i];

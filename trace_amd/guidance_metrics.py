@@ -228,10 +228,25 @@ class MapCollisionGuidance(GuidanceMetric):
     plan was made on (guidance_metrics.py:340-391; metrics.batch_detect_off_road_boxes).  Raster coordinates in
     fp32 with the reference's operation order (the pixel index is a truncation)."""
 
+    def reset(self):
+        super().reset()
+        self._raster = self._raster_rows = None
+
     def _record(self, state_info, h, lo, hi):
         rows = np.arange(lo, hi) if self.agents is None else lo + self.agents
+        # Only the metric's own rows of a raster batch are kept (flattened, on the raster's device), sliced once per
+        # raster object: a long closed loop would otherwise pin one full (agents, H, W) batch per replan.  The latest
+        # batch object itself stays referenced so that the next frame can tell whether the raster changed.
+        drv = state_info["drivable_map"]
+        if self._raster is not drv:
+            self._raster = drv
+            if torch.is_tensor(drv):
+                m = drv.reshape(drv.shape[0], -1)[torch.as_tensor(rows, device=drv.device)].clone()
+            else:
+                m = np.asarray(drv).reshape(np.asarray(drv).shape[0], -1)[rows].copy()
+            self._raster_rows = (m, int(drv.shape[-2]), int(drv.shape[-1]))
         return (h["centroid"][rows], h["yaw"][rows], h["extent"][rows], h["raster_from_world"][rows],
-                state_info["drivable_map"], rows)
+                self._raster_rows, rows)
 
     def _points(self, ctr, yaw, ext):
         return _box_corners(ctr, yaw, ext)                                   # (F, n, 4, 2)
@@ -254,16 +269,14 @@ class MapCollisionGuidance(GuidanceMetric):
             hy = rfw[..., 1, 0] * np.cos(yaw) + rfw[..., 1, 1] * np.sin(yaw)
             pix_per_m = np.linalg.norm(rfw[..., :2, 0], axis=-1).astype(np.float32)  # get_raster_pix2m() of the reference
             pts = self._points(ctr, np.arctan2(hy, hx).astype(np.float32), ext * pix_per_m[..., None])
-            drv, rows = fr[0][4], fr[0][5]
-            H, W = drv.shape[-2], drv.shape[-1]
+            (m, H, W), rows = fr[0][4], fr[0][5]
             x = np.clip(pts[..., 0], 0, W - 1).astype(np.int64)              # metrics.batch_detect_off_road
             y = np.clip(pts[..., 1], 0, H - 1).astype(np.int64)
             idx = np.moveaxis(y * W + x, 0, 1).reshape(len(rows), -1)        # (n, F * k)
-            if torch.is_tensor(drv):
-                m = drv.reshape(drv.shape[0], -1)[torch.as_tensor(rows, device=drv.device)]
-                val = torch.gather(m.float(), 1, torch.as_tensor(idx, device=drv.device)).cpu().numpy()
+            if torch.is_tensor(m):
+                val = torch.gather(m.float(), 1, torch.as_tensor(idx, device=m.device)).cpu().numpy()
             else:
-                val = np.take_along_axis(np.asarray(drv).reshape(drv.shape[0], -1)[rows].astype(np.float32), idx, 1)
+                val = np.take_along_axis(m.astype(np.float32), idx, 1)
             offp = (1.0 - val).reshape(len(rows), len(fr), -1)               # (n, F, k): 1 where off road
             off.append((offp.sum(-1) > 0.5).astype(np.float64))
             i = j
