@@ -301,13 +301,14 @@ int trace_guide_map_collision_argmin(const float* traj, float* grad_traj, float*
  * assigned neighbour of its group per (sample, step) -- the nearest member, or the member the caller
  * drew at random (the reference draws torch.randint / torch.rand inside the loss, :803-804; here the
  * draw is an argument so that it can be injected).  The leader's positions are constants (:775-776).
- *   members (n_agents, TRACE_SOCIAL_GROUP_WIDTH) int32: global agent indices of the agent's group in
- *     group order, -1 padded (rows of agents outside any group: all -1, scale 0)
+ *   members (n_agents, group_width) int32: global agent indices of the agent's group in group order, -1 padded
+ *     (rows of agents outside any group: all -1, scale 0); group_width >= the largest group
  *   is_leader (n_agents) int32; pick (M, T) int32 or NULL: >= 0 = global index of the assigned
  *     neighbour, -1 = nearest
  *   workspace: M*T*4 floats (world poses); nbr_ws: M*T int32; dist_ws: M*T floats
- * loss[m] = mean_t (dist - social_dist)^2; groups are limited to TRACE_SOCIAL_GROUP_WIDTH members (the
- * range in which torch.cdist evaluates distances exactly). */
+ * loss[m] = mean_t (dist - social_dist)^2.  Groups of up to TRACE_SOCIAL_GROUP_WIDTH members take the exact
+ * distance, larger ones the matmul form torch.cdist switches to above 25 points (guidance_loss.py:786,
+ * SURVEY.md appendix A), evaluated in ATen's operation order. */
 #define TRACE_SOCIAL_GROUP_WIDTH 25
 int trace_guide_social_group(const float* traj, float* grad_traj, float* loss,
                              const float* world_from_agent, const int* members, int group_width,

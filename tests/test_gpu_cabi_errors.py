@@ -127,7 +127,7 @@ def test_env_rasterize_and_social_group_reject_bad_arguments(sampler):
     assert rc == EINVAL and "scale + offset" in _err(L)
     assert L.trace_env_rasterize(pose.data_ptr(), soa.data_ptr(), boxes.data_ptr(), 1, C.byref(rfa), img.data_ptr(), 2,
                                  drv.data_ptr(), 0, 8, 8, None) == 0          # no agents: nothing to do
-    # social group: the members table must have the ABI's width
+    # social group: a members table narrower than two columns cannot hold a group
     M, T = 4, 52
     traj = torch.zeros(M, T, 6, device=dev)
     loss = torch.zeros(M, device=dev)
@@ -138,10 +138,10 @@ def test_env_rasterize_and_social_group_reject_bad_arguments(sampler):
     ws = torch.empty(M * T * 4, device=dev)
     nbr = torch.empty(M * T, dtype=torch.int32, device=dev)
     dist = torch.empty(M * T, device=dev)
-    rc = L.trace_guide_social_group(traj.data_ptr(), None, loss.data_ptr(), wfa.data_ptr(), members.data_ptr(), 8,
+    rc = L.trace_guide_social_group(traj.data_ptr(), None, loss.data_ptr(), wfa.data_ptr(), members.data_ptr(), 1,
                                     lead.data_ptr(), None, 1.5, scale.data_ptr(), 2, 2, T, ws.data_ptr(),
                                     nbr.data_ptr(), dist.data_ptr(), None)
-    assert rc == EINVAL and "wide" in _err(L)
+    assert rc == EINVAL and "width" in _err(L)
     rc = L.trace_guide_social_group(traj.data_ptr(), None, loss.data_ptr(), wfa.data_ptr(), members.data_ptr(), 25,
                                     lead.data_ptr(), None, 1.5, scale.data_ptr(), 2, 2, T, None,
                                     nbr.data_ptr(), dist.data_ptr(), None)

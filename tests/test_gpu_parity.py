@@ -567,6 +567,39 @@ def test_social_group_value_and_grad(env):
     assert float(g[..., 2:].abs().max()) == 0.0                                    # positions only
 
 
+def test_large_social_group_value_and_grad(env):
+    """A social group of 28 / 30 members (above 25 torch.cdist takes its matmul form, guidance_loss.py:786): the HIP
+    kernels against the reference's golden with the reference's draws injected, next to a 2-member group in the
+    exact form.  The matmul form carries ~1e-4 relative noise at these coordinates; the kernel restates ATen's
+    operation order, so the nearest-neighbour choices -- and with them loss and gradient -- agree."""
+    from oracle.gen_golden_social_large import APS, large_configs
+    from trace_amd.guidance import DiffuserGuidance
+    cfg = env["cfg"]
+    batch = syn.make_batch(cfg, APS, seed=3, extent=(0.9, 0.7, 1.75), dense=True)
+    gold = dict(np.load(os.path.join(GOLDEN, "social_group_large.npz")))
+    traj0 = torch.tensor(gold["traj"])
+    B, N, T = traj0.shape[:3]
+    td = traj0.reshape(B * N, T, 6).to(DEV).contiguous()
+    for name, cfgs in large_configs().items():
+        plan = DiffuserGuidance(cfgs).build_plan(batch, N, T, DEV)
+        widths = sorted(int(ly["dev"]["members"].shape[1]) for ly in plan.layers)
+        assert widths == ([25, 32] if name == "large_mixed" else [32]), widths
+        plan.social_tape = {k[len(name) + len("/randint/"):]: (torch.tensor(gold[k]).long(),
+                                                              torch.tensor(gold[k.replace("/randint/", "/rand/")]))
+                            for k in gold if k.startswith(name + "/randint/")}
+        gt = torch.zeros(B * N, T, 6, device=DEV)
+        losses = plan.guide_losses(plan.evaluate(td, gt, None))
+        for k in plan.social_tape:
+            want = torch.tensor(gold["%s/per/%s" % (name, k)])
+            got = losses[k].cpu()
+            assert torch.equal(torch.isnan(got), torch.isnan(want)), (name, k)
+            assert _rel(torch.nan_to_num(got), torch.nan_to_num(want)) < 1e-5, (name, k, _rel(torch.nan_to_num(got), torch.nan_to_num(want)))
+        gref = torch.tensor(gold[name + "/grad"])
+        scale = float(gref.abs().max())
+        err = float((gt.cpu().reshape(B, N, T, 6) - gref).abs().max()) / scale
+        assert scale > 0 and err < 1e-4, (name, err)
+
+
 def test_sampler_with_social_group_guidance(env):
     """Clean-guided sampling steps with social_group + target_pos guidance: HIP sampler vs CPU oracle
     with the same (static) neighbour draws injected on both sides."""

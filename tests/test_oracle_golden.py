@@ -155,3 +155,28 @@ def test_social_group_vs_reference_golden(setup):
         for k, v in per.items():
             assert torch.equal(torch.nan_to_num(v), torch.nan_to_num(torch.tensor(gold["%s/per/%s" % (name, k)])))
         assert float(gt.abs().max()) > 0
+
+
+def test_large_social_group_vs_reference_golden(setup):
+    """SocialGroupLoss on a group of 28 / 30 members: above 25 torch.cdist takes its matmul form
+    (guidance_loss.py:786); tests/golden/social_group_large.npz, written by oracle/gen_golden_social_large.py."""
+    from oracle.gen_golden_social_large import APS, large_configs
+    cfg = setup[0]
+    batch = syn.make_batch(cfg, APS, seed=3, extent=(0.9, 0.7, 1.75), dense=True)
+    gold = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "social_group_large.npz")))
+    traj0 = torch.tensor(gold["traj"])
+    for name, cfgs in large_configs().items():
+        guid = orc.Guidance(cfgs)
+        for si, cur in enumerate(guid.scenes):
+            for gi, (gname, _, _, fn) in enumerate(cur):
+                key = "%s_scene_%03d_%02d" % (gname, si, gi)
+                fn.draw = (torch.tensor(gold["%s/randint/%s" % (name, key)]).long(),
+                           torch.tensor(gold["%s/rand/%s" % (name, key)]))
+        tr = traj0.clone().requires_grad_()
+        tot, per = guid.loss(tr, batch)
+        gt, = torch.autograd.grad(tot, tr)
+        assert torch.equal(tot.detach(), torch.tensor(gold[name + "/total"])), name
+        assert torch.equal(gt, torch.tensor(gold[name + "/grad"])), name
+        for k, v in per.items():
+            assert torch.equal(torch.nan_to_num(v), torch.nan_to_num(torch.tensor(gold["%s/per/%s" % (name, k)])))
+        assert float(gt.abs().max()) > 0

@@ -409,11 +409,14 @@ __global__ __launch_bounds__(256) void map_collision_kernel(
 // detached: it is pulled by nobody and pulls its followers.
 //   members[ag * G + s]  global agent index of the s-th member of ag's group (-1 = padding)
 //   pick[m * T + t]      >= 0: global index of the randomly assigned neighbour; -1: nearest
-// pass 1: nbr[m*T+t] (global agent index) and dist[m*T+t]; distances in the exact cdist form
-// (groups of <= 25 members keep ATen out of its matmul mode).
-template <int G>
+// pass 1: nbr[m*T+t] (global agent index) and dist[m*T+t].  The distance takes the form torch.cdist takes for the
+// group's size (guidance_loss.py:786): the exact one up to TRACE_SOCIAL_GROUP_WIDTH = 25
+// members, above that ATen's matmul form |a|^2 + |b|^2 - 2ab, evaluated as the k-ordered fma chain of its K = 4
+// matmul (row = this member, column = the other one; the chain of map_collision_kernel) and clamped at 0 before the
+// root -- the form decides which member is the nearest when two candidates are within its rounding noise.
+// G = width of the members table (>= the largest group).
 __global__ __launch_bounds__(256) void social_neighbor_kernel(
-    const float* __restrict__ ws, const int* __restrict__ members, const int* __restrict__ pick,
+    const float* __restrict__ ws, const int* __restrict__ members, int G, const int* __restrict__ pick,
     int* __restrict__ nbr, float* __restrict__ dist, const float* __restrict__ scale, int M,
     int num_samp, int T) {
   TRAJ_PROLOGUE();
@@ -422,15 +425,30 @@ __global__ __launch_bounds__(256) void social_neighbor_kernel(
   const size_t i = (size_t)m * T + lane;
   const float4 me = reinterpret_cast<const float4*>(ws)[i];
   const int forced = pick ? pick[i] : -1;
+  int cnt = 0;
+#pragma unroll 1
+  for (int s = 0; s < G; ++s) cnt += members[(size_t)ag * G + s] >= 0 ? 1 : 0;
+  const bool matmul_form = cnt > TRACE_SOCIAL_GROUP_WIDTH;
+  const float an = me.x * me.x + me.y * me.y;
   float best = INFINITY;
   int bj = -1;
 #pragma unroll 1
   for (int s = 0; s < G; ++s) {
-    const int j = members[ag * G + s];
+    const int j = members[(size_t)ag * G + s];
     if (j < 0 || j == ag) continue;
     const float4 ot = reinterpret_cast<const float4*>(ws)[((size_t)j * num_samp + n) * T + lane];
-    const float ex = me.x - ot.x, ey = me.y - ot.y;
-    const float d = sqrtf(ex * ex + ey * ey);
+    float d;
+    if (matmul_form) {
+      const float bn = ot.x * ot.x + ot.y * ot.y;
+      float acc = (-2.f * me.x) * ot.x;
+      acc = fmaf(-2.f * me.y, ot.y, acc);
+      acc = acc + an;
+      acc = acc + bn;
+      d = sqrtf(fmaxf(acc, 0.f));
+    } else {
+      const float ex = me.x - ot.x, ey = me.y - ot.y;
+      d = sqrtf(ex * ex + ey * ey);
+    }
     if (forced >= 0 ? j == forced : d < best) { best = d; bj = j; }
   }
   nbr[i] = bj;
@@ -439,10 +457,9 @@ __global__ __launch_bounds__(256) void social_neighbor_kernel(
 
 // pass 2: loss and owner-computes gradient: lane (ag, n, t) collects its own row's pull towards its
 // neighbour and the pull of every member whose assigned neighbour it is.
-template <int G>
 __global__ __launch_bounds__(256) void social_group_kernel(
     const float* __restrict__ ws, float* __restrict__ grad, float* __restrict__ loss,
-    const float* __restrict__ wfa, const int* __restrict__ members, const int* __restrict__ is_leader,
+    const float* __restrict__ wfa, const int* __restrict__ members, int G, const int* __restrict__ is_leader,
     const int* __restrict__ nbr, const float* __restrict__ dist, float social_dist,
     const float* __restrict__ scale, int M, int num_samp, int T) {
   TRAJ_PROLOGUE();
@@ -467,7 +484,7 @@ __global__ __launch_bounds__(256) void social_group_kernel(
   }
 #pragma unroll 1
   for (int s = 0; s < G; ++s) {
-    const int o = members[ag * G + s];
+    const int o = members[(size_t)ag * G + s];
     if (o < 0 || o == ag) continue;
     const size_t io = ((size_t)o * num_samp + n) * T + tl;
     if (nbr[io] != ag) continue;
@@ -690,19 +707,18 @@ extern "C" int trace_guide_social_group(const float* traj, float* grad_traj, flo
   GUIDE_COMMON_CHECK("trace_guide_social_group");
   TRACE_REQUIRE(world_from_agent && members && is_leader && workspace && nbr_ws && dist_ws,
                 "trace_guide_social_group: null table");
-  TRACE_REQUIRE(group_width == TRACE_SOCIAL_GROUP_WIDTH, "trace_guide_social_group: members table must be %d wide",
-                TRACE_SOCIAL_GROUP_WIDTH);
+  TRACE_REQUIRE(group_width >= 2 && group_width <= n_agents + TRACE_SOCIAL_GROUP_WIDTH,
+                "trace_guide_social_group: members table of width %d for %d agents", group_width, n_agents);
   int n = M * T;
   hipLaunchKernelGGL(world_pose_kernel, dim3((n + 255) / 256), dim3(256), 0, st, traj,
                      world_from_agent, workspace, n, num_samp, T);
   int rc = launch_status("world_pose_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(social_neighbor_kernel<TRACE_SOCIAL_GROUP_WIDTH>, grid, block, 0, st, workspace, members,
-                     pick, nbr_ws, dist_ws, scale, M, num_samp, T);
+  hipLaunchKernelGGL(social_neighbor_kernel, grid, block, 0, st, workspace, members, group_width, pick, nbr_ws,
+                     dist_ws, scale, M, num_samp, T);
   rc = launch_status("social_neighbor_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(social_group_kernel<TRACE_SOCIAL_GROUP_WIDTH>, grid, block, 0, st, workspace, grad_traj,
-                     loss, world_from_agent, members, is_leader, nbr_ws, dist_ws, social_dist, scale, M,
-                     num_samp, T);
+  hipLaunchKernelGGL(social_group_kernel, grid, block, 0, st, workspace, grad_traj, loss, world_from_agent, members,
+                     group_width, is_leader, nbr_ws, dist_ws, social_dist, scale, M, num_samp, T);
   return launch_status("social_group_kernel");
 }

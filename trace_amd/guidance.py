@@ -19,7 +19,7 @@ GUIDANCE_NAMES = ("target_speed", "agent_collision", "map_collision", "target_po
                   "target_pos", "global_target_pos_at_time", "global_target_pos", "min_speed",
                   "social_group")
 _UNSUPPORTED = {"amp_value": "needs an external value function (guidance_loss.py:816-849)"}
-SOCIAL_GROUP_WIDTH = 25          # TRACE_SOCIAL_GROUP_WIDTH of include/trace_hip.h
+SOCIAL_GROUP_WIDTH = 25          # TRACE_SOCIAL_GROUP_WIDTH of include/trace_hip.h: up to here the exact distance form
 SCENE_LEVEL = ("agent_collision", "social_group")
 
 
@@ -341,16 +341,16 @@ class GuidancePlan:
             if nm < 2:
                 raise ValueError("social_group needs at least two agents (the reference draws "
                                  "torch.randint(0, B-1), guidance_loss.py:803)")
-            if nm > SOCIAL_GROUP_WIDTH:
-                raise NotImplementedError("social_group of %d agents: groups above %d members put torch.cdist "
-                                          "into its matmul mode (SURVEY.md appendix A); not built"
-                                          % (nm, SOCIAL_GROUP_WIDTH))
+            # members table: 25 wide (every group the exact distance form covers), or the group's size rounded up to
+            # a multiple of 8 (the kernel switches to torch.cdist's matmul form by the member count, as ATen does);
+            # the width is part of the layer key, so tables of different widths never share a launch
+            width = SOCIAL_GROUP_WIDTH if nm <= SOCIAL_GROUP_WIDTH else (nm + 7) // 8 * 8
             idx = torch.nonzero(mask, as_tuple=True)[0]                    # group order = batch order
-            members = torch.full((nm, SOCIAL_GROUP_WIDTH), -1, dtype=torch.int32)
+            members = torch.full((nm, width), -1, dtype=torch.int32)
             members[:, :nm] = idx.to(torch.int32)[None]
             # the reference compares the BATCH index with leader_idx (guidance_loss.py:775): kept
             leader = (idx == int(p.get("leader_idx", 0))).to(torch.int32)
-            return [_Item("social_group", ("social_group", float(p.get("social_dist", 1.5))), mask,
+            return [_Item("social_group", ("social_group", float(p.get("social_dist", 1.5)), width), mask,
                           {"scale": sc, "members": members, "is_leader": leader,
                            "cohesion": torch.full((nm,), coh, dtype=torch.float32),
                            "gsize": torch.full((nm,), nm, dtype=torch.int64),
@@ -455,7 +455,7 @@ class GuidancePlan:
                 pick = self._social_pick(ly)
                 rc = L.trace_guide_social_group(
                     ptr(traj), gp, ptr(loss), ptr(self.world_from_agent), ptr(d["members"]),
-                    SOCIAL_GROUP_WIDTH, ptr(d["is_leader"]), ptr(pick), ly["key"][1], ptr(d["scale"]),
+                    int(d["members"].shape[1]), ptr(d["is_leader"]), ptr(pick), ly["key"][1], ptr(d["scale"]),
                     self.B, N, T, ptr(self.ws), ptr(self.nbr_ws), ptr(self.dist_ws), stream)
             else:
                 raise AssertionError(kind)
@@ -500,7 +500,7 @@ class GuidancePlan:
             u = torch.rand(B, N, T, device=dev, generator=self.generator)
         rs = r + (r >= slot[:, None, None]).to(torch.int64)             # skip self in the choice list
         cand = torch.gather(d["members"].to(torch.int64), 1,
-                            rs.reshape(B, N * T).clamp(max=SOCIAL_GROUP_WIDTH - 1)).reshape(B, N, T)
+                            rs.reshape(B, N * T).clamp(max=d["members"].shape[1] - 1)).reshape(B, N, T)
         take = u < d["cohesion"][:, None, None]
         return torch.where(take, cand, torch.full_like(cand, -1)).to(torch.int32).contiguous()
 
