@@ -457,7 +457,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
           t1 += d;
           t2 = fmaf(d, x, t2);
         }
+#ifndef TRACE_NO_ROWSUM_FENCE
         asm volatile("" : "+v"(t1), "+v"(t2));      // same guard as the forward moments
+#endif
         s1[j] = t1;
         s2[j] = t2;
       }
@@ -576,7 +578,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
         // (v_pk_add_f32 chains fed by v_mov pairs of just-returned LDS registers behind partial
         // s_waitcnt lgkmcnt(N)) lanes 48..63 of the sums differed from run to run on gfx950 (DESIGN.md
         // section 5.1, "run-to-run differences"); the opaque use keeps the sums scalar whatever the flags.
+#ifndef TRACE_NO_ROWSUM_FENCE      // diagnostic builds only (profiles/r3_groupnorm_isa_*): variant A of DESIGN.md section 5.1
         asm volatile("" : "+v"(rm), "+v"(q));
+#endif
         rmean[j] = rm;
         m2[j] = q;
         gs[j] = rm;

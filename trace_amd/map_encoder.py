@@ -210,7 +210,13 @@ class MapEncoder:
     @torch.no_grad()
     def __call__(self, image):
         x = image.to(device=self.device, dtype=torch.float32)
-        if self.backend == "hip" and tuple(x.shape[2:]) == (224, 224) and x.shape[1] <= 8:
+        if self.backend == "hip":
+            # no silent second path: the kernels are built for TRACE's rasters (224 x 224, 2 ORCA / 7 nuScenes
+            # channels); anything else has to ask for the PyTorch form by name
+            if tuple(x.shape[2:]) != (224, 224) or x.shape[1] > 8:
+                raise ValueError("map encoder (hip backend): rasters of shape %s are not built (224 x 224, at most 8 "
+                                 "channels); construct MapEncoder(..., backend='torch') for other shapes"
+                                 % (tuple(x.shape[1:]),))
             return None, self._forward_hip(x.contiguous())
         nhwc = self.device.type == "cuda" and x.shape[0] >= self.channels_last_from
         if nhwc:
@@ -263,7 +269,10 @@ class MapEncoder:
         is torchvision's and stays unpinned."""
         feats = [f.to(device=self.device, dtype=torch.float32) for f in feats]
         assert len(feats) == 4 and [f.shape[1] for f in feats] == [64, 128, 256, 512], [f.shape for f in feats]
-        if self.backend == "hip" and tuple(feats[0].shape[2:]) == (56, 56):
+        if self.backend == "hip":
+            if tuple(feats[0].shape[2:]) != (56, 56):
+                raise ValueError("map decoder (hip backend): layer1 features of %s are not built (56 x 56); "
+                                 "construct MapEncoder(..., backend='torch') for other shapes" % (tuple(feats[0].shape),))
             return self._decode_hip(feats)
         self.p = self._p_nchw
         return self._decode(feats)
