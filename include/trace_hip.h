@@ -169,6 +169,13 @@ typedef struct {
 int trace_map_query(const float* x, const float* grid, const float* raster_from_agent,
                     float* x_in, int M, int num_samp, int T, int C, int Hg, int Wg, int c_pad,
                     float img_w, float img_h, const trace_dyn_params* p, void* stream);
+/* The same for both halves of a classifier-free call in ONE launch: the reference queries the conditioned and
+ * the unconditioned grid one after the other (tbsim/models/trace.py:570,578-583); rows 0..M-1 of x_in take
+ * `grid`, rows M..2M-1 `grid_non_cond` (same x, same bilinear weights). */
+int trace_map_query_cfg(const float* x, const float* grid, const float* grid_non_cond,
+                        const float* raster_from_agent, float* x_in, int M, int num_samp, int T, int C,
+                        int Hg, int Wg, int c_pad, float img_w, float img_h, const trace_dyn_params* p,
+                        void* stream);
 
 /* Unicycle action->state rollout, mode='parallel'
  * (tbsim/models/trace_helpers.py:387-475; wrapper tbsim/models/trace.py:390-413).
@@ -209,6 +216,13 @@ int trace_posterior_step(const float* x0, const float* grad, const float* x, con
                          const float* curr_states, float* x_next, float* a_out, int M,
                          int num_samp, int T, int clean, const trace_step_coefs* c,
                          const trace_dyn_params* p, void* stream);
+/* The same with the input gradient of a classifier-free call given as its two halves (the reference's autograd
+ * sums the gradients of the conditioned and the unconditioned denoiser pass into x, tbsim/models/trace.py:578-596,
+ * 674-676): grad = grad_cond + grad_non_cond, formed here instead of by a kernel of its own. */
+int trace_posterior_step_cfg(const float* x0, const float* grad_cond, const float* grad_non_cond,
+                             const float* x, const float* noise, const float* curr_states, float* x_next,
+                             float* a_out, int M, int num_samp, int T, int clean, const trace_step_coefs* c,
+                             const trace_dyn_params* p, void* stream);
 
 /* ------------------------------------------------------ guidance objectives ---- */
 /* All objectives read the descaled trajectory traj (M,T,6), ADD their weighted gradient into

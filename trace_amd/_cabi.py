@@ -65,6 +65,10 @@ PROTOTYPES = {
     "trace_profile_pipe_seconds": (C.c_double, []),
     "trace_map_query": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F,
                              C.POINTER(DynParams), _P]),
+    "trace_map_query_cfg": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _F,
+                                 C.POINTER(DynParams), _P]),
+    "trace_posterior_step_cfg": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I,
+                                      C.POINTER(StepCoefs), C.POINTER(DynParams), _P]),
     "trace_dyn_rollout": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, C.POINTER(DynParams), _P]),
     "trace_dyn_adjoint": (_I, [_P, _P, _P, _P, _I, _I, _I, C.POINTER(DynParams), _P]),
     "trace_cfg_combine": (_I, [_P, _P, _P, _P, _I, _I, _F, C.POINTER(StepCoefs), _P]),

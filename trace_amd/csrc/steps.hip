@@ -181,10 +181,10 @@ __global__ void posterior_mean_kernel(const float* __restrict__ x0, const float*
 
 // tbsim/models/trace.py:653-704
 __global__ __launch_bounds__(256) void posterior_step_kernel(
-    const float* __restrict__ x0, const float* __restrict__ grad, const float* __restrict__ x,
-    const float* __restrict__ noise, const float* __restrict__ curr, float* __restrict__ x_next,
-    float* __restrict__ a_out, int M, int num_samp, int T, int clean, trace_step_coefs c,
-    trace_dyn_params p) {
+    const float* __restrict__ x0, const float* __restrict__ grad, const float* __restrict__ grad2,
+    const float* __restrict__ x, const float* __restrict__ noise, const float* __restrict__ curr,
+    float* __restrict__ x_next, float* __restrict__ a_out, int M, int num_samp, int T, int clean,
+    trace_step_coefs c, trace_dyn_params p) {
   const int lane = threadIdx.x & 63;
   const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -197,7 +197,8 @@ __global__ __launch_bounds__(256) void posterior_step_kernel(
     for (int j = 0; j < 2; ++j) {
       size_t i = ((size_t)m * T + lane) * 2 + j;
       float xt = x[((size_t)m * T + lane) * 6 + 4 + j];
-      float gm = grad ? nz * grad[i] : 0.f;
+      // grad2: the classifier-free half of the input gradient, summed first as `gx[:M] + gx[M:]` does
+      float gm = grad ? nz * (grad2 ? grad[i] + grad2[i] : grad[i]) : 0.f;
       float nt = (nz * sigma) * noise[i];
       float v;
       if (clean) {
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256) void posterior_step_kernel(
 // grid is channels-last (n_agents, Hg, Wg, C): the C features of a pixel are one 128-B line.
 __global__ __launch_bounds__(256) void map_query_kernel(const float* __restrict__ x,
                                                         const float* __restrict__ grid,
+                                                        const float* __restrict__ grid2,
                                                         const float* __restrict__ rfa,
                                                         float* __restrict__ x_in, int M,
                                                         int num_samp, int T, int C, int Hg, int Wg,
@@ -254,7 +256,8 @@ __global__ __launch_bounds__(256) void map_query_kernel(const float* __restrict_
     base[tid] = (int)y0f * Wg + (int)x0f;
   }
   __syncthreads();
-  const float* gb = grid + (size_t)ag * Hg * Wg * C;
+  // blockIdx.y = 1: the unconditioned half of a classifier-free call (rows M .. 2M - 1 of x_in, features of grid2)
+  const float* gb = (blockIdx.y ? grid2 : grid) + (size_t)ag * Hg * Wg * C;
   for (int e = tid; e < T * C; e += 256) {
     int t = e / C, ch = e - t * C;
     const float* g0 = gb + (size_t)base[t] * C + ch;
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(256) void map_query_kernel(const float* __restrict_
     tile[ch * T + t] = v;
   }
   __syncthreads();
-  float* ob = x_in + (size_t)m * c_pad * T;
+  float* ob = x_in + ((size_t)blockIdx.y * M + m) * c_pad * T;
   for (int e = tid; e < 6 * T; e += 256) {
     int j = e / T, t = e - j * T;
     ob[e] = x[((size_t)m * T + t) * 6 + j];
@@ -275,6 +278,16 @@ __global__ __launch_bounds__(256) void map_query_kernel(const float* __restrict_
 
 using namespace trace;
 
+static int map_query_impl(const float* x, const float* grid, const float* grid2, const float* raster_from_agent,
+                          float* x_in, int M, int num_samp, int T, int C, int Hg, int Wg, int c_pad, float img_w,
+                          float img_h, const trace_dyn_params* p, void* stream) {
+  size_t sm = (size_t)(5 * T + C * T) * sizeof(float);
+  hipLaunchKernelGGL(map_query_kernel, dim3(M, grid2 ? 2 : 1), dim3(256), sm, (hipStream_t)stream, x, grid, grid2,
+                     raster_from_agent, x_in, M, num_samp, T, C, Hg, Wg, c_pad, (float)Wg / img_w,
+                     (float)Hg / img_h, *p);
+  return launch_status("map_query_kernel");
+}
+
 extern "C" int trace_map_query(const float* x, const float* grid, const float* raster_from_agent,
                                float* x_in, int M, int num_samp, int T, int C, int Hg, int Wg,
                                int c_pad, float img_w, float img_h, const trace_dyn_params* p,
@@ -283,11 +296,20 @@ extern "C" int trace_map_query(const float* x, const float* grid, const float* r
   TRACE_REQUIRE(M >= 0 && num_samp > 0 && T > 0 && T <= 64 && C > 0 && 6 + C <= c_pad,
                 "trace_map_query: bad shape M=%d T=%d C=%d c_pad=%d", M, T, C, c_pad);
   if (M == 0) return TRACE_OK;
-  size_t sm = (size_t)(5 * T + C * T) * sizeof(float);
-  hipLaunchKernelGGL(map_query_kernel, dim3(M), dim3(256), sm, (hipStream_t)stream, x, grid,
-                     raster_from_agent, x_in, M, num_samp, T, C, Hg, Wg, c_pad, (float)Wg / img_w,
-                     (float)Hg / img_h, *p);
-  return launch_status("map_query_kernel");
+  return map_query_impl(x, grid, nullptr, raster_from_agent, x_in, M, num_samp, T, C, Hg, Wg, c_pad, img_w, img_h, p,
+                        stream);
+}
+
+extern "C" int trace_map_query_cfg(const float* x, const float* grid, const float* grid_non_cond,
+                                   const float* raster_from_agent, float* x_in, int M, int num_samp, int T,
+                                   int C, int Hg, int Wg, int c_pad, float img_w, float img_h,
+                                   const trace_dyn_params* p, void* stream) {
+  TRACE_REQUIRE(x && grid && grid_non_cond && raster_from_agent && x_in && p, "trace_map_query_cfg: null argument");
+  TRACE_REQUIRE(M >= 0 && num_samp > 0 && T > 0 && T <= 64 && C > 0 && 6 + C <= c_pad,
+                "trace_map_query_cfg: bad shape M=%d T=%d C=%d c_pad=%d", M, T, C, c_pad);
+  if (M == 0) return TRACE_OK;
+  return map_query_impl(x, grid, grid_non_cond, raster_from_agent, x_in, M, num_samp, T, C, Hg, Wg, c_pad, img_w,
+                        img_h, p, stream);
 }
 
 extern "C" int trace_dyn_rollout(const float* actions, const float* curr_states, float* out, int M,
@@ -370,7 +392,21 @@ extern "C" int trace_posterior_step(const float* x0, const float* grad, const fl
   TRACE_REQUIRE(x != x_next, "trace_posterior_step: x_next must not alias x");
   if (M == 0) return TRACE_OK;
   hipLaunchKernelGGL(posterior_step_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                     x0, grad, x, noise, curr_states, x_next, a_out, M, num_samp, T, clean, *c, *p);
+                     x0, grad, nullptr, x, noise, curr_states, x_next, a_out, M, num_samp, T, clean, *c, *p);
+  return launch_status("posterior_step_kernel");
+}
+
+extern "C" int trace_posterior_step_cfg(const float* x0, const float* grad_cond, const float* grad_non_cond,
+                                        const float* x, const float* noise, const float* curr_states,
+                                        float* x_next, float* a_out, int M, int num_samp, int T, int clean,
+                                        const trace_step_coefs* c, const trace_dyn_params* p, void* stream) {
+  TRACE_REQUIRE(x0 && grad_cond && grad_non_cond && x && noise && curr_states && x_next && c && p,
+                "trace_posterior_step_cfg: null argument");
+  TRACE_REQUIRE(M >= 0 && num_samp > 0 && T > 0 && T <= 64, "trace_posterior_step_cfg: bad shape");
+  TRACE_REQUIRE(x != x_next, "trace_posterior_step_cfg: x_next must not alias x");
+  if (M == 0) return TRACE_OK;
+  hipLaunchKernelGGL(posterior_step_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x0, grad_cond,
+                     grad_non_cond, x, noise, curr_states, x_next, a_out, M, num_samp, T, clean, *c, *p);
   return launch_status("posterior_step_kernel");
 }
 

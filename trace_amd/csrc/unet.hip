@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
                                                           float* __restrict__ dy, int C, int cg,
                                                           int rows, const float* __restrict__ head_g,
                                                           const float* __restrict__ head_w,
-                                                          float* __restrict__ gscale) {
+                                                          float* __restrict__ gscale,
+                                                          unsigned* __restrict__ dy_amax) {
   const int ngroups = C / cg;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);      // wave-uniform
   const int row = unit / ngroups;
@@ -186,11 +187,18 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
   const float inv_n = 1.f / (float)n;
   s1 = wave_sum(s1) * inv_n;
   s2 = wave_sum(s2) * inv_n;
+  float mo = 0.f;
 #pragma unroll
   for (int k = 0; k < MAXE; ++k) {
     int e = lane + k * 64;
-    if (e < n) ob[e] = rstd * (gg[k] - s1 - xh[k] * s2);
+    if (e < n) {
+      const float o = rstd * (gg[k] - s1 - xh[k] * s2);
+      ob[e] = o;
+      mo = fmaxf(mo, fabsf(o));
+    }
   }
+  // the consumer (the final block's dgrad conv) runs on the fp16-pair scheme when it knows its input's scale
+  if (dy_amax) record_amax(dy_amax, row & ~15, mo);
 }
 
 // final 1x1 conv (C -> 2) + transpose:  pred[row][t][o] = b[o] + sum_c W[o][c] f[row][c][t]
@@ -957,12 +965,13 @@ void set_res2(ConvArgs& a, const View& r) {
 
 int run_gn_bwd(const View& da, const float* y, const float* stats, const float* gamma,
                const float* beta, float* dy, int C, int L, int rows, hipStream_t st,
-               const float* head_g = nullptr, const float* head_w = nullptr, float* gscale = nullptr) {
+               const float* head_g = nullptr, const float* head_w = nullptr, float* gscale = nullptr,
+               unsigned* dy_amax = nullptr) {
   int cg = C / 8;
   dim3 grid((rows * 8 + 3) / 4);
 #define GNB(LL)                                                                              \
   hipLaunchKernelGGL(gn_mish_bwd_kernel<LL>, grid, dim3(256), 0, st, da.p, da.tstride(), da.coff, \
-                     y, stats, gamma, beta, dy, C, cg, rows, head_g, head_w, gscale)
+                     y, stats, gamma, beta, dy, C, cg, rows, head_g, head_w, gscale, dy_amax)
   if (L == 52) GNB(52);
   else if (L == 26) GNB(26);
   else if (L == 13) GNB(13);
@@ -1250,8 +1259,9 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred_a
   // head + final block
   {
     View g0 = view(iG0, d0, 0, H), g1 = produced(iG1, d0, 0, H);
-    View t1 = view(iT1, d0, 0, H);                      // written by gn_mish_bwd_kernel: no amax
-    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, t1.p, d0, H, rows, st, grad_pred, u->head_w, gscale));
+    View t1 = produced(iT1, d0, 0, H);                  // written by gn_mish_bwd_kernel, which records its amax too
+    RUN(run_gn_bwd(g0, buf(u->b_yf), buf(u->b_sf), u->fg, u->fbe, t1.p, d0, H, rows, st, grad_pred, u->head_w, gscale,
+                   conv_scheme(-1) ? t1.amax : nullptr));
     RUN(run_conv(K_CONV5, H, conv_args(t1, u->final_b, nullptr, g1, rows), st));
   }
   // up1 (ConvT d0: L/2 -> L): its dgrad output is dout of block 11

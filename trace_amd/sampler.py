@@ -252,12 +252,13 @@ class TraceSampler:
                 sc = self._coefs(t)
                 csc = C.byref(sc)
                 # denoiser input: trajectory + bilinear map features, cond and uncond rows stacked
-                _cabi.check(L.trace_map_query(ptr(x), ptr(grid), ptr(rfa), ptr(x_in), M, N, T, Cg, Hg, Wg,
-                                              C_PAD, img_w, img_h, dyn, st_), "trace_map_query")
                 if use_cfg:
-                    _cabi.check(L.trace_map_query(ptr(x), ptr(grid_nc), ptr(rfa), x_in[M:].data_ptr(), M,
-                                                  N, T, Cg, Hg, Wg, C_PAD, img_w, img_h, dyn, st_),
-                                "trace_map_query")
+                    _cabi.check(L.trace_map_query_cfg(ptr(x), ptr(grid), ptr(grid_nc), ptr(rfa), ptr(x_in), M, N,
+                                                      T, Cg, Hg, Wg, C_PAD, img_w, img_h, dyn, st_),
+                                "trace_map_query_cfg")
+                else:
+                    _cabi.check(L.trace_map_query(ptr(x), ptr(grid), ptr(rfa), ptr(x_in), M, N, T, Cg, Hg, Wg,
+                                                  C_PAD, img_w, img_h, dyn, st_), "trace_map_query")
                 _cabi.check(L.trace_unet_forward(self._unet, ptr(x_in), ptr(table), N, t, R, ptr(pred),
                                                  ptr(ws), ws_bytes, save, st_), "trace_unet_forward")
                 _cabi.check(L.trace_cfg_combine(ptr(pred), pred[M:].data_ptr() if use_cfg else None,
@@ -282,14 +283,20 @@ class TraceSampler:
                             csc, st_), "trace_cfg_combine_adjoint")
                         _cabi.check(L.trace_unet_backward_input(self._unet, ptr(gpred), R, ptr(gx), ptr(ws),
                                                                 ws_bytes, st_), "trace_unet_backward_input")
-                        grad = gx[:M] + gx[M:] if use_cfg else gx
+                        grad = gx
                     else:
                         grad = g_act
                 clean_path = 1 if (plan_ is not None and guide_clean) else 0
-                _cabi.check(L.trace_posterior_step(ptr(x0), ptr(grad) if grad is not None else None,
-                                                   ptr(x), ptr(noise[k]), ptr(curr), ptr(x_next),
-                                                   ptr(a_out), M, N, T, clean_path, csc, dyn, st_),
-                            "trace_posterior_step")
+                if grad is not None and grad is gx and use_cfg:      # both halves of the input gradient, summed inside the kernel
+                    _cabi.check(L.trace_posterior_step_cfg(ptr(x0), ptr(gx), gx[M:].data_ptr(), ptr(x),
+                                                           ptr(noise[k]), ptr(curr), ptr(x_next), ptr(a_out), M, N,
+                                                           T, clean_path, csc, dyn, st_),
+                                "trace_posterior_step_cfg")
+                else:
+                    _cabi.check(L.trace_posterior_step(ptr(x0), ptr(grad) if grad is not None else None,
+                                                       ptr(x), ptr(noise[k]), ptr(curr), ptr(x_next),
+                                                       ptr(a_out), M, N, T, clean_path, csc, dyn, st_),
+                                "trace_posterior_step")
                 if plan_ is not None and k == S - 1:
                     # guidance losses of the final sample, for filtering (trace.py:697-700)
                     _cabi.check(L.trace_dyn_rollout(ptr(a_out), ptr(curr), ptr(traj), M, N, T, 1, 0, dyn,
