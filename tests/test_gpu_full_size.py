@@ -9,7 +9,8 @@ whole batch:
     choice (hence summation order) depends on the batch size, so the bar is 2e-5, not equality;
   * spot check against the oracle -- two of the eight scenes (1280 of the 5120 trajectories) of
     the full-batch result are compared with the CPU oracle run on those scenes only, stepping from
-    the same x_t with the same noise (3 reverse steps in the middle of the schedule);
+    the same x_t with the same noise (3 reverse steps in the middle of the schedule); and every one of
+    the eight scenes for ONE reverse step each, two scenes per step at t = 99, 70, 30 and 0, at 1e-4;
   * determinism -- the same call twice gives identical bits;
   * a dense single scene (configs[2] shape: 128 agents, agent-collision guidance) against the
     oracle on the SAME inputs for one reverse step (the B x B pair loop at its full width).
@@ -104,6 +105,30 @@ def test_two_scenes_of_the_full_batch_match_the_oracle(full):
         worst = max(worst, rel)
     # 1e-4 relative per step (north_star); three chained guided steps
     assert worst < 3e-4, worst
+
+
+@pytest.mark.parametrize("t,scenes", [(99, (0, 2)), (70, (2, 4)), (30, (4, 6)), (0, (6, 8))])
+def test_every_scene_of_the_full_batch_matches_the_oracle_for_one_step(full, t, scenes):
+    """All eight scenes of the full batch (5120 trajectories, 10240 denoiser rows), two per diffusion step: ONE
+    guided reverse step at t = 99 (first), 70, 30 and 0 (last: no noise, no guidance) from the same x_t, the
+    full-batch HIP result against the CPU oracle run on those two scenes -- north_star's 1e-4 relative per step."""
+    f = full
+    cfg, N = f["cfg"], f["N"]
+    g = torch.Generator().manual_seed(1000 + t)
+    noise = torch.randn(1, f["x0"].shape[0], cfg.horizon, 2, generator=g)
+    out = f["s"].forward(f["batch"], num_samp=N, class_free_guide_w=0.5, guide_clean=True, x_init=f["x0"],
+                         steps=[t], noise_steps=noise)
+    res = out["pred_traj_scaled"].reshape(f["res"].shape).cpu()
+    o = orc.OracleSampler(cfg, f["sd"])
+    sub, (a0, a1) = slice_batch(f["batch"], f["aps"], scenes)
+    o.set_guidance(slice_guidance(f["guidance"], scenes))
+    aux = o.repeat_aux(orc.get_aux_info(o.sd, cfg, sub, True), N)
+    x = f["x0"][a0 * N:a1 * N]
+    tt = torch.full((x.shape[0],), t, dtype=torch.long)
+    ref, _ = o.p_sample(x, tt, sub, aux, N, 0.5, noise[0, a0 * N:a1 * N], True, True, eval_final=False)
+    got = res[a0 * N:a1 * N]
+    rel = float(((got - ref).abs() / (1.0 + ref.abs())).max())
+    assert torch.isfinite(got).all() and rel < 1e-4, (t, rel)
 
 
 def test_dense_scene_agent_collision_step_matches_the_oracle():
