@@ -21,14 +21,14 @@ python3 scripts/step_trace.py "$DB" 50 > "$OUT/one_ddpm_step_launches.txt" || tr
 echo "stats done"
 
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 150 rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o p -- python3 scripts/prof_unet.py 10240 2 > "$OUT/pmc_$C.log" 2>&1
+  timeout -s KILL 150 rocprofv3 --pmc $C -d "$OUT/pmc_$C" -o p -- python3 scripts/prof_unet.py 10240 2 bwd nosplit > "$OUT/pmc_$C.log" 2>&1
   DB=$(find "$OUT/pmc_$C" -name '*results.db' | head -n 1)
   python3 scripts/rocpd_summary.py pmc "$DB" > "$OUT/unet_pmc_$C.csv"
   echo "$C done"
 done
 
 timeout -s KILL 150 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE \
-    -d "$OUT/pmc_SQ" -o p -- python3 scripts/prof_unet.py 10240 2 > "$OUT/pmc_SQ.log" 2>&1
+    -d "$OUT/pmc_SQ" -o p -- python3 scripts/prof_unet.py 10240 2 bwd nosplit > "$OUT/pmc_SQ.log" 2>&1
 DB=$(find "$OUT/pmc_SQ" -name '*results.db' | head -n 1)
 python3 scripts/rocpd_summary.py pmc "$DB" > "$OUT/unet_pmc_SQ.csv"
 echo "SQ done"
