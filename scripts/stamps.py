@@ -21,7 +21,7 @@ from trace_amd.config import ModelConfig                      # noqa: E402
 from trace_amd.sampler import TraceSampler, C_PAD             # noqa: E402
 from trace_amd.weights import random_state_dict               # noqa: E402
 
-rows = 10240
+rows = int(os.environ.get("STAMP_ROWS", "10240"))
 cfg = ModelConfig()
 s = TraceSampler(cfg, random_state_dict(cfg, 0), "cuda:0")
 L = s.lib

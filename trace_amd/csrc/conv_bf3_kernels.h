@@ -290,6 +290,10 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
   // one chunk's MFMAs over taps [T0, T1); the next chunk's activations (chunk `next`, -1 = none) are
   // requested one staging unit at a time between row tiles, after the slice's weight loads, so that
   // neither the issue of 32 loads in a row nor a vmcnt wait for weights stalls on them
+#ifdef TRACE_STAMP_SLICES       // diagnostic (scripts/stamps_slices.py): per-slice / per-tile stamps of chunks 1 and 2, wave 0
+  int stamp_ch = -1;
+#define TRACE_SLICE_STAMP(k) do { if (a.dbg && threadIdx.x == 0) a.dbg[131072 + (size_t)blockIdx.x * 64 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#endif
   auto chunk_mma = [&](auto t0c, auto t1c, auto nrc, const int next, auto halfc) {
     constexpr int T0 = decltype(t0c)::value, T1 = decltype(t1c)::value, NR = decltype(nrc)::value;
     constexpr int HALF = decltype(halfc)::value;                               // k-slice of the chunk: octets 4 HALF ..
@@ -308,6 +312,13 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
     bf16x8 b[NPL];
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
+#ifdef TRACE_STAMP_SLICES
+      if (n % NR == 0) {
+        if (stamp_ch == 1) TRACE_SLICE_STAMP(HALF * (T1 - T0) + n / NR);
+        else if (stamp_ch == 2) TRACE_SLICE_STAMP(16 + HALF * (T1 - T0) + n / NR);
+      }
+      if (stamp_ch == 1 && HALF == 0 && n / NR == 2) TRACE_SLICE_STAMP(32 + n % NR);
+#endif
       if (n % NR == 0) {
         if constexpr (WPF >= 2) {
 #pragma unroll
@@ -344,7 +355,11 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #define TRACE_BF3_LOAD_SPREAD 0   // row tiles between the global loads of two staging units of the next chunk (0: all at once)
 #endif
       if constexpr (TRACE_BF3_LOAD_SPREAD == 0) {
+#ifdef TRACE_EXP_NOSTAGELOAD      // timing-only build: the next chunk's loads are never issued (its data is garbage)
+        if (false) {
+#else
         if (n == 1) {
+#endif
 #pragma unroll
           for (int j = J0; j < J1; ++j) stage_load_unit(next, j);
         }
@@ -424,6 +439,9 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #else
     const int next = ch + 1 < nch ? ch + 1 : (SPLITK ? ch : -1);
 #endif
+#ifdef TRACE_STAMP_SLICES
+    stamp_ch = ch;
+#endif
     using IC0 = std::integral_constant<int, 0>;
     using ICT = std::integral_constant<int, TAPS>;
     using ICP = std::integral_constant<int, PADL>;
@@ -445,6 +463,10 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
         else chunk_mma(ICP{}, ICP1{}, NRC2{}, next, IC0{});
       }
     }
+#ifdef TRACE_STAMP_SLICES
+    if (ch == 1) TRACE_SLICE_STAMP(10);
+    else if (ch == 2) TRACE_SLICE_STAMP(26);
+#endif
     // stamps 2, 3: first two chunks; 4, 5: last two (scripts/stamps.py takes the last as the K end)
     if (ch < 2) TRACE_STAMP(2 + ch);
 #ifndef TRACE_STAMP_SWITCH
