@@ -382,6 +382,48 @@ def test_every_denoiser_buffer_is_bit_reproducible(full):
     assert float(runs[0][3].view(torch.float32).abs().max()) > 0
 
 
+@pytest.mark.parametrize("rows", [320, 1000, 2560])
+def test_small_launch_tiles_give_the_same_bits_as_full_tiles(full, rows):
+    """Launches of at most one full tile per CU run on HALF tiles (Bf3Geom: 104 rows per workgroup, three weight
+    slices in flight; conv_bf3_kernels.h launch_conv_bf3).  The first `rows` rows of a 10240-row denoiser call (full
+    tiles, two row halves on two streams) and a call on those rows alone (half tiles at every level for 320 rows, at
+    some levels for 1000 / 2560) must agree bit for bit: prediction and input gradient.  This holds because every
+    floating-point contraction of the epilogues is spelled out (common.h mish_fast_f, conv_epilogue)."""
+    from trace_amd import _cabi
+    f = full
+    s, cfg, N = f["s"], f["cfg"], f["N"]
+    L = _cabi.lib()
+    R = 10240
+    g = torch.Generator().manual_seed(77)
+    from trace_amd.sampler import C_PAD
+    x_in = torch.zeros(R, C_PAD, cfg.horizon)
+    x_in[:, :38] = torch.randn(R, 38, cfg.horizon, generator=g)
+    x_in = x_in.to(DEV)
+    cond = torch.randn(R // N, 256, generator=g).to(DEV)
+    table = torch.empty(R // N, s.cond_width, device=DEV)
+    _cabi.check(L.trace_unet_cond_table(s._unet, cond.data_ptr(), R // N, table.data_ptr(), None))
+    gp = torch.randn(R, cfg.horizon, 2, generator=g).to(DEV)
+
+    def run(n):
+        wsb = L.trace_unet_workspace_bytes(s._unet, n, 1)
+        ws = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+        pred = torch.zeros(n, cfg.horizon, 2, device=DEV)
+        gx = torch.zeros(n, cfg.horizon, 2, device=DEV)
+        xi, gpi = x_in[:n].contiguous(), gp[:n].contiguous()
+        _cabi.check(L.trace_unet_forward(s._unet, xi.data_ptr(), table.data_ptr(), N, 37, n, pred.data_ptr(),
+                                         ws.data_ptr(), wsb, 1, None), "trace_unet_forward")
+        _cabi.check(L.trace_unet_backward_input(s._unet, gpi.data_ptr(), n, gx.data_ptr(), ws.data_ptr(), wsb, None),
+                    "trace_unet_backward_input")
+        torch.cuda.synchronize()
+        return pred, gx
+
+    pf, gf = run(R)
+    ps, gs = run(rows)
+    assert torch.isfinite(pf).all() and torch.isfinite(gf).all()
+    assert torch.equal(ps, pf[:rows]), int((ps != pf[:rows]).sum())
+    assert torch.equal(gs, gf[:rows]), int((gs != gf[:rows]).sum())
+
+
 def test_wave_specialised_conv_kernel_gives_the_same_bits(full):
     """conv_ws_kernel (persistent, wave-specialised; csrc/conv_ws_kernels.h, opt-in through trace_conv_ws_mode) against
     the default conv_bf3_kernel: every buffer of the denoiser workspace after the forward and after the input-VJP,

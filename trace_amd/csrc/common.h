@@ -82,12 +82,16 @@ __device__ __forceinline__ float mish_f(float x) {
 // the small-K layers they follow.  A bare v_exp_f32(x*log2e) loses |x|*6e-8 relative to the
 // rounding of the product (the noisy-guidance loop amplifies that beyond the parity bar), so the
 // product's rounding error and the low part of log2(e) are fed back through e^d ~ 1 + d.
+// Every fused multiply-add of these two functions is spelled out and the compiler's own contraction is off:
+// left to itself it fused a different subset of the candidates per element and per kernel instantiation, so the
+// same activation came out 1 ulp apart in the full-tile and the half-tile conv kernels (round 3).
 __device__ __forceinline__ float mish_fast_f(float x) {
+#pragma clang fp contract(off)
   const float L2E_HI = 1.44269502162933349609375f;   // float(log2 e)
   const float L2E_LO = 1.92596299112661746e-8f;      // log2 e - L2E_HI
   float xc = fminf(x, 20.f);
   float p = xc * L2E_HI;
-  float d = __builtin_fmaf(xc, L2E_HI, -p) + xc * L2E_LO;      // exact remainder of the product
+  float d = __builtin_fmaf(xc, L2E_LO, __builtin_fmaf(xc, L2E_HI, -p));      // exact remainder of the product + low part
   float e = __builtin_amdgcn_exp2f(p);
   e = __builtin_fmaf(e, d * 0.693147182464599609375f, e);
   float n = e * (e + 2.f);
@@ -112,11 +116,12 @@ __device__ __forceinline__ float mish_grad_f(float x) {
 // mish'(x) on the hardware transcendental units, same compensated exponent and Newton-refined
 // reciprocals as mish_fast_f (fused GroupNorm/Mish backward epilogue of the dgrad convs).
 __device__ __forceinline__ float mish_grad_fast_f(float x) {
+#pragma clang fp contract(off)
   const float L2E_HI = 1.44269502162933349609375f;
   const float L2E_LO = 1.92596299112661746e-8f;
   float xc = fminf(x, 20.f);
   float p = xc * L2E_HI;
-  float d = __builtin_fmaf(xc, L2E_HI, -p) + xc * L2E_LO;
+  float d = __builtin_fmaf(xc, L2E_LO, __builtin_fmaf(xc, L2E_HI, -p));
   float e = __builtin_amdgcn_exp2f(p);
   e = __builtin_fmaf(e, d * 0.693147182464599609375f, e);
   float n = e * (e + 2.f);

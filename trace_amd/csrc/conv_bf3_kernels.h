@@ -49,18 +49,24 @@ struct Bf3Geom {
   static constexpr int CH = CHN;                           // channels per chunk = CH / 32 MFMA k-slices per tap
   static constexpr int NOCT = CH / 8;                      // channel octets = (plane, octet) arrays per plane
   static constexpr int NPLMAX = CHN == 32 ? 3 : 2;         // 64-channel chunks exist for the two-plane scheme only
-  static constexpr int R = TB * L_OUT;
-  static constexpr int NRT = R / 16;
-  static constexpr int PPT = L_OUT / NRT;                  // positions per row tile (4, 2, 1)
+  static constexpr int R = TB * L_OUT;                     // output rows of the workgroup (the epilogue's tile)
+  static constexpr int PPT = 16 / TB;                      // positions per row tile (8, 4, 2, 1)
+  static constexpr int NRT = (L_OUT + PPT - 1) / PPT;      // row tiles
+  // Full tiles (TB L_OUT = 208: L = 13 / 26 / 52 with TB = 16 / 8 / 4) have NRT PPT = L_OUT.  HALF tiles (TB = 8 / 4 /
+  // 2: 104 rows, launches of at most one workgroup per CU -- twice as many workgroups, each with half the serial
+  // chain) have 7 row tiles whose last one is half phantom: positions L_OUT .. LPOS - 1 read zero halo cells and
+  // their accumulators are never written (conv_epilogue E0).
+  static constexpr int LPOS = NRT * PPT;
   // Row tile rt = positions PPT rt .. + PPT - 1 of all TB trajectories (MFMA row i = trajectory * PPT +
   // position offset), so the 16 rows of an LDS read sit at cells trajectory * LP + const: LP is the
   // staged positions per trajectory, padded until those 16 cells fall into 16 different 16-byte
-  // slots modulo 16 (TB = 4: LP = 4 or 12 mod 16; TB = 8: LP / 2 odd; TB = 16: LP odd).
+  // slots modulo 16 (TB = 2: LP = 8 mod 16; TB = 4: LP = 4 or 12 mod 16; TB = 8: LP / 2 odd; TB = 16: LP odd).
   static constexpr int lp_pad(int lp) {
-    while (!(TB == 4 ? (lp % 16 == 4 || lp % 16 == 12) : TB == 8 ? (lp % 2 == 0 && (lp / 2) % 2 == 1) : lp % 2 == 1)) ++lp;
+    while (!(TB == 2 ? lp % 16 == 8 : TB == 4 ? (lp % 16 == 4 || lp % 16 == 12)
+                                    : TB == 8 ? (lp % 2 == 0 && (lp / 2) % 2 == 1) : lp % 2 == 1)) ++lp;
     return lp;
   }
-  static constexpr int LP = lp_pad((L_OUT - 1) * IS + TAPS);
+  static constexpr int LP = lp_pad((LPOS - 1) * IS + TAPS);
   static constexpr int S = TB * LP;
   static constexpr int L_IN = L_OUT * IS / UP;
   static constexpr int SUB = (S * 16 + 255) / 256 * 256;   // bytes of one (plane, channel octet) array
@@ -73,7 +79,7 @@ struct Bf3Geom {
   // the output tile (conv_epilogue)
   static constexpr size_t EPI_BYTES = (size_t)R * 64 * sizeof(float);
   static constexpr size_t LDS_BYTES = (size_t)NPLMAX * PLANE > EPI_BYTES ? (size_t)NPLMAX * PLANE : EPI_BYTES;
-  static_assert(R % 16 == 0 && L_OUT % UP == 0 && TB % 4 == 0 && PPT * NRT == L_OUT && PPT * TB == 16, "bad tile");
+  static_assert(L_OUT % UP == 0 && (TB == 2 || TB == 4 || TB == 8 || TB == 16) && PPT * TB == 16 && (R * 64) % 4 == 0, "bad tile");
   static_assert(PLANE + NOCT * SUB < 131072, "plane offsets stay small");
 };
 
@@ -278,12 +284,16 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
 #ifndef TRACE_BF3_NST
 #define TRACE_BF3_NST 4           // A-fragment register stages (prefetch distance + 1)
 #endif
-  bf16x8 bn1[NPL], bn2[NPL];
+  // WPF weight slices in flight ahead of the one being multiplied: bn[0] is the next slice, bn[WPF - 1] the newest
+  // request.  Full-chip launches keep one (the co-resident wave covers an L2 round trip and the registers are
+  // needed elsewhere); a lone workgroup per CU waits a full L2 / Infinity-Cache round trip per slice with one,
+  // so half tiles (at most one workgroup per CU, <= 181 VGPRs) keep more
+  constexpr int WPFN = WPF < 1 ? 1 : WPF;
+  bf16x8 bn[WPFN][NPL];
 #pragma unroll
-  for (int p = 0; p < NPL; ++p) bn1[p] = wp[64 * p];
-  if constexpr (WPF >= 2) {
+  for (int i = 0; i < WPFN; ++i) {
 #pragma unroll
-    for (int p = 0; p < NPL; ++p) bn2[p] = a.nsl > 1 ? wp[WSL + 64 * p] : bn1[p];
+    for (int p = 0; p < NPL; ++p) bn[i][p] = (i == 0 || i < a.nsl) ? wp[i * WSL + 64 * p] : bn[0][p];
   }
   int sdone = 0;
 
@@ -320,27 +330,21 @@ __device__ __forceinline__ void conv_bf3_body(const ConvArgs& a, const int rb, c
       if (stamp_ch == 1 && HALF == 0 && n / NR == 2) TRACE_SLICE_STAMP(32 + n % NR);
 #endif
       if (n % NR == 0) {
-        if constexpr (WPF >= 2) {
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) { b[p] = bn1[p]; bn1[p] = bn2[p]; }
-          ++sdone;
-          wp += WSL;
-          if (sdone + 1 < a.nsl) {
+        for (int p = 0; p < NPL; ++p) b[p] = bn[0][p];
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) bn2[p] = wp[WSL + 64 * p];
-          }
-        } else {
+        for (int i = 0; i + 1 < WPFN; ++i) {
 #pragma unroll
-          for (int p = 0; p < NPL; ++p) b[p] = bn1[p];
-          ++sdone;
-          wp += WSL;
-#ifndef TRACE_EXP_NOWLOAD
-          if (sdone < a.nsl) {
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) bn1[p] = wp[64 * p];
-          }
-#endif
+          for (int p = 0; p < NPL; ++p) bn[i][p] = bn[i + 1][p];
         }
+        ++sdone;
+        wp += WSL;
+#ifndef TRACE_EXP_NOWLOAD
+        if (sdone + WPFN - 1 < a.nsl) {
+#pragma unroll
+          for (int p = 0; p < NPL; ++p) bn[WPFN - 1][p] = wp[(WPFN - 1) * WSL + 64 * p];
+        }
+#endif
       }
 #ifdef TRACE_EXP_NOLDSREAD         // timing-only build: the A fragments of the first tiles are reused
       if (n + DIST < NT && n + DIST < NST) load_a(n + DIST, (n + DIST) % NST);
@@ -504,19 +508,36 @@ __global__ __launch_bounds__(NW * 64, MINW) void conv_bf3_kernel(ConvArgs a) {
 // A residual block's first k5 conv (a) and its 1x1 residual conv (b) read the same input: one launch, the column
 // tiles of b behind those of a in every row block, so the 1x1 workgroups run beside the k5 workgroups of their
 // row block (same XCD: the input comes from L2) and fill matrix-pipe time the memory-bound 1x1 launch left idle.
-template <int L_OUT, int TB, int CHN>
+template <int L_OUT, int TB, int CHN, int WPF = TRACE_BF3_WPF>
 __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvArgs a, ConvArgs b) {
   const int ncol_a = a.cout >> 6;
   const int ncol = ncol_a + (b.cout >> 6);
   const int bid = blockIdx.x;
   const int rb = (bid / (8 * ncol)) * 8 + (bid & 7);
   const int ct = (bid >> 3) % ncol;
-  if (ct < ncol_a) conv_bf3_body<L_OUT, 1, 5, 2, TB, 1, 4, 2, CHN, 1>(a, rb, ct);
-  else conv_bf3_body<L_OUT, 1, 1, 0, TB, 1, 4, 2, 32, 1>(b, rb, ct - ncol_a);
+  if (ct < ncol_a) conv_bf3_body<L_OUT, 1, 5, 2, TB, 1, 4, 2, CHN, 1, WPF>(a, rb, ct);
+  else conv_bf3_body<L_OUT, 1, 1, 0, TB, 1, 4, 2, 32, 1, WPF>(b, rb, ct - ncol_a);
 }
 
-template <int L_OUT, int TB>
+#ifndef TRACE_HALF_TILES
+#define TRACE_HALF_TILES 1        // launches of at most SMALL_WGS full tiles run on half tiles (Bf3Geom)
+#endif
+#ifndef TRACE_HALF_WPF
+#define TRACE_HALF_WPF 3          // weight slices in flight on half tiles (cfg1: 1 -> 74.6, 2 -> 66.2, 3 -> 65.7, 4 -> 65.8 ms per call)
+#endif
+#ifndef TRACE_HALF_KIND
+#define TRACE_HALF_KIND 7         // diagnostic: bit 0 pair launches, bit 1 stride-2 launches, bit 2 the others
+#endif
+#ifndef TRACE_HALF_L
+#define TRACE_HALF_L 0            // diagnostic: half tiles at this L_OUT only (0 = every length)
+#endif
+constexpr long SMALL_WGS = 256;   // one workgroup per CU
+template <int L_OUT, int TB, bool MAY_HALVE = true>
 int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
+  if constexpr (MAY_HALVE && TRACE_HALF_TILES && (TRACE_HALF_KIND & 1) && TB >= 4 && (TRACE_HALF_L == 0 || TRACE_HALF_L == L_OUT)) {
+    if ((long)((a.rows + TB - 1) / TB) * ((a.cout + b.cout) / 64) <= SMALL_WGS)
+      return launch_conv_pair<L_OUT, TB / 2, false>(a, b, st);
+  }
   constexpr int CHN = 64;
   using GA = Bf3Geom<L_OUT, 1, 5, 2, TB, 4, CHN, 1>;
   using GB = Bf3Geom<L_OUT, 1, 1, 0, TB, 4, 32, 1>;
@@ -542,12 +563,12 @@ int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
   constexpr size_t lds_bytes = la > lb ? la : lb;
   static_assert(lds_bytes <= 80 * 1024, "conv pair: LDS per workgroup too large for two per CU");
   static unsigned long long attr_done = 0;
-  TRACE_CHECK_HIP(ensure_dynamic_lds(&attr_done, reinterpret_cast<const void*>(&conv_pair_kernel<L_OUT, TB, CHN>), 100 * 1024));
+  TRACE_CHECK_HIP(ensure_dynamic_lds(&attr_done, reinterpret_cast<const void*>(&conv_pair_kernel<L_OUT, TB, CHN, (MAY_HALVE ? TRACE_BF3_WPF : TRACE_HALF_WPF)>), 100 * 1024));
   const int nrb = (a.rows + TB - 1) / TB;
   dim3 grid(((nrb + 7) / 8) * 8 * ((a.cout + b.cout) / 64));
   const bool prof = prof_active();
   if (prof) prof_pre(st);
-  hipLaunchKernelGGL((conv_pair_kernel<L_OUT, TB, CHN>), grid, dim3(256), lds_bytes, st, a, b);
+  hipLaunchKernelGGL((conv_pair_kernel<L_OUT, TB, CHN, (MAY_HALVE ? TRACE_BF3_WPF : TRACE_HALF_WPF)>), grid, dim3(256), lds_bytes, st, a, b);
   if (prof) {
     const double fl = 2.0 * (a.alg_macs_per_pos + b.alg_macs_per_pos) * (double)a.rows * L_OUT;
     prof_post(st, fl, fl * 3.0 / PEAK_MFMA16_FLOPS);
@@ -627,31 +648,40 @@ int conv_ws_mode(int mode);                                    // unet.hip (trac
 int conv_scheme(int mode);                                     // unet.hip (trace_conv_scheme): 0 bf16 x 3, 1 fp16 x 2 where possible
 
 // stride-2 convs (32-channel chunks: a chunk already stages 2 L_OUT positions per trajectory)
-template <int L_OUT, int TAPS, int PADL, int TB>
+template <int L_OUT, int TAPS, int PADL, int TB, bool MAY_HALVE = true>
 int launch_conv_bf3_s2(const ConvArgs& a, hipStream_t st) {
+  if constexpr (MAY_HALVE && TRACE_HALF_TILES && (TRACE_HALF_KIND & 2) && TB >= 4 && (TRACE_HALF_L == 0 || TRACE_HALF_L == L_OUT)) {
+    if ((long)((a.rows + TB - 1) / TB) * (a.cout / 64) <= SMALL_WGS)
+      return launch_conv_bf3_s2<L_OUT, TAPS, PADL, TB / 2, false>(a, st);
+  }
   constexpr int MW = TRACE_BF3_WGS * TRACE_BF3_NW / 4;
   if (a.wh && a.in_amax)
     return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 32, 2>(a, st);
   return launch_conv_bf3_impl<L_OUT, 1, TAPS, PADL, TB, 0, TRACE_BF3_NW, MW, 32, 2>(a, st);
 }
 
-template <int L_OUT, int UP, int TAPS, int PADL, int TB>
+template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool MAY_HALVE = true>
 int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
   constexpr int MW = TRACE_BF3_WGS * TRACE_BF3_NW / 4;
   const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
+  if constexpr (MAY_HALVE && TRACE_HALF_TILES && (TRACE_HALF_KIND & 4) && TB >= 4 && (TRACE_HALF_L == 0 || TRACE_HALF_L == L_OUT)) {
+    if (wgs <= SMALL_WGS) return launch_conv_bf3<L_OUT, UP, TAPS, PADL, TB / 2, false>(a, st);
+  }
   if (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax)) {          // every operand has its scale: the fp16 pipe
 #ifndef TRACE_F16_CH
 #define TRACE_F16_CH 64           // channels per chunk of the fp16 launches with more than one tap (32 / 64; build switch)
 #endif
     if constexpr (TAPS > 1 && TRACE_F16_CH == 64) {
       if (a.cin % 64 == 0 && a.cin2 % 64 == 0)
-        return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 64>(a, st);
+        return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 64, 1, (MAY_HALVE ? TRACE_BF3_WPF : TRACE_HALF_WPF)>(a, st);
     }
-    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1>(a, st);
+    return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 32, 1, (MAY_HALVE ? TRACE_BF3_WPF : TRACE_HALF_WPF)>(a, st);
   }
   if constexpr (TAPS > 1) {
-    if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > 256 && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.head_pred)
-      return launch_conv_ws<L_OUT, UP, TAPS, PADL, TB>(a, st);
+    if constexpr (MAY_HALVE) {             // full tiles only
+      if (conv_ws_mode(-1) && !conv_scheme(-1) && wgs > 256 && (a.cin / 32 + a.cin2 / 32) % 2 == 0 && !a.head_pred)
+        return launch_conv_ws<L_OUT, UP, TAPS, PADL, TB>(a, st);
+    }
   }
   return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 0>(a, st);
 }

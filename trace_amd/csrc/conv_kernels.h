@@ -266,7 +266,10 @@ template <int L_OUT, int TB, int ROWMAP = 0, int NW = 4, int NACC = TB * L_OUT /
 __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NACC], float* lds,
                                               const int traj0, const int co0, const int rt0 = 0,
                                               const int nrtw = NACC, const float oscale = 1.f) {
-  constexpr int R = TB * L_OUT, NRT = R / 16;
+  // explicit FMAs only: the epilogue's arithmetic must not depend on which candidates the compiler contracts in
+  // this instantiation (common.h, mish_fast_f)
+#pragma clang fp contract(off)
+  constexpr int R = TB * L_OUT;
   constexpr int TILE = 64 * L_OUT;
   constexpr int NTH = NW * 64;                       // threads of the workgroup
   constexpr int NF4 = R * 64 / 4;                    // 16-byte cells of the output tile
@@ -339,17 +342,46 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[NA
       if (ri >= nrtw) break;
       const int rt = rt0 + ri;
       if constexpr (ROWMAP == 1) {
-        constexpr int PPT = L_OUT / NRT;
-        static_assert(PPT * NRT == L_OUT && PPT * TB == 16 && (PPT == 1 || PPT == 2 || PPT == 4),
-                      "trajectory-major tiles need L_OUT = 13 PPT and TB = 16 / PPT");
+        // row tile rt = positions PPT rt .. PPT rt + PPT - 1 of all TB trajectories; a half tile's last row tile
+        // reaches past L_OUT (Bf3Geom::LPOS): those phantom positions are never written
+        constexpr int PPT = 16 / TB;
+        static_assert(PPT * TB == 16 && (PPT == 1 || PPT == 2 || PPT == 4 || PPT == 8),
+                      "trajectory-major tiles: TB = 16 / PPT trajectories");
         f32x4 v = acc[ri];                      // oscale: the fp16 scheme's power of two (1 otherwise: exact)
         v[0] = fmaf(v[0], oscale, bv); v[1] = fmaf(v[1], oscale, bv);
         v[2] = fmaf(v[2], oscale, bv); v[3] = fmaf(v[3], oscale, bv);
-        if constexpr (PPT == 4) {               // lane group q = trajectory, registers = 4 positions
-          *reinterpret_cast<f32x4*>(tcol + q * TILE + 4 * rt) = v;
+        if constexpr (PPT == 8) {               // lane groups 2t, 2t + 1 = trajectory t, registers = 4 of its 8 positions
+          const int p0 = 8 * rt + 4 * (q & 1);
+          if (p0 < L_OUT) *reinterpret_cast<f32x4*>(tcol + (q >> 1) * TILE + p0) = v;
+        } else if constexpr (PPT == 4) {        // lane group q = trajectory, registers = 4 positions
+          if (4 * rt + 3 < L_OUT) {
+            if constexpr (L_OUT % 4 == 0) {
+              *reinterpret_cast<f32x4*>(tcol + q * TILE + 4 * rt) = v;
+            } else {                            // rows of L_OUT = 26 floats start at 8-byte boundaries only
+              *reinterpret_cast<float2*>(tcol + q * TILE + 4 * rt) = float2{v[0], v[1]};
+              *reinterpret_cast<float2*>(tcol + q * TILE + 4 * rt + 2) = float2{v[2], v[3]};
+            }
+          } else {                              // L_OUT = 26 on half tiles: two positions left
+            if constexpr (L_OUT % 4 == 2) {
+              *reinterpret_cast<float2*>(tcol + q * TILE + 4 * rt) = float2{v[0], v[1]};
+            } else {
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg)
+                if (4 * rt + reg < L_OUT) tcol[q * TILE + 4 * rt + reg] = v[reg];
+            }
+          }
         } else if constexpr (PPT == 2) {        // registers 0,1 / 2,3 = two positions of trajectories 2q / 2q+1
-          *reinterpret_cast<float2*>(tcol + (2 * q) * TILE + 2 * rt) = float2{v[0], v[1]};
-          *reinterpret_cast<float2*>(tcol + (2 * q + 1) * TILE + 2 * rt) = float2{v[2], v[3]};
+          if constexpr (L_OUT % 2 == 0) {
+            *reinterpret_cast<float2*>(tcol + (2 * q) * TILE + 2 * rt) = float2{v[0], v[1]};
+            *reinterpret_cast<float2*>(tcol + (2 * q + 1) * TILE + 2 * rt) = float2{v[2], v[3]};
+          } else {                              // L_OUT = 13 on half tiles: rows start at odd offsets, last position single
+            tcol[(2 * q) * TILE + 2 * rt] = v[0];
+            tcol[(2 * q + 1) * TILE + 2 * rt] = v[2];
+            if (2 * rt + 1 < L_OUT) {
+              tcol[(2 * q) * TILE + 2 * rt + 1] = v[1];
+              tcol[(2 * q + 1) * TILE + 2 * rt + 1] = v[3];
+            }
+          }
         } else {                                // registers = trajectories 4q .. 4q+3, one position
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) tcol[(4 * q + reg) * TILE + rt] = v[reg];

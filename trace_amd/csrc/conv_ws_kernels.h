@@ -44,6 +44,7 @@ struct WsGeom {
 template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool GNB>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void conv_ws_kernel(ConvArgs a, int ntv) {
+#pragma clang fp contract(off)      // explicit FMAs only, as conv_epilogue (conv_kernels.h): the two must agree bit for bit
   using G = Bf3Geom<L_OUT, UP, TAPS, PADL, TB, 4>;
   constexpr int LP = G::LP, L_IN = G::L_IN, SUB = G::SUB, PLANE = G::PLANE;
   constexpr int NUT = G::NUT, NU = G::NU, NPOS = G::NPOS, CH = G::CH, PPT = G::PPT;

@@ -124,6 +124,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
                                                           const float* __restrict__ head_w,
                                                           float* __restrict__ gscale,
                                                           unsigned* __restrict__ dy_amax) {
+#pragma clang fp contract(off)                               // explicit FMAs only, as the fused epilogues (conv_kernels.h)
   const int ngroups = C / cg;
   const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);      // wave-uniform
   const int row = unit / ngroups;
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
       int c = e / L;
       float x = (yb[e] - mean) * rstd;
       float ga = gamma[g * cg + c];
-      float z = x * ga + beta[g * cg + c];
+      float z = __builtin_fmaf(x, ga, beta[g * cg + c]);
       // the final block's upstream gradient is the 1x1 head's dgrad, W^T g (head_g (rows, L, 2)):
       // formed here instead of by a kernel of its own
       float up;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
       gg[k] = gz;
       xh[k] = x;
       s1 += gz;
-      s2 += gz * x;
+      s2 = __builtin_fmaf(gz, x, s2);
     }
   }
   const float inv_n = 1.f / (float)n;
