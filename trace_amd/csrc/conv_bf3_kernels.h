@@ -531,7 +531,10 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvArgs a, ConvArgs 
 #ifndef TRACE_HALF_L
 #define TRACE_HALF_L 0            // diagnostic: half tiles at this L_OUT only (0 = every length)
 #endif
-constexpr long SMALL_WGS = 256;   // one workgroup per CU
+#ifndef TRACE_SMALL_WGS
+#define TRACE_SMALL_WGS 256       // full tiles of a launch up to which it runs on half tiles (256 = one workgroup per CU)
+#endif
+constexpr long SMALL_WGS = TRACE_SMALL_WGS;
 template <int L_OUT, int TB, bool MAY_HALVE = true>
 int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
   if constexpr (MAY_HALVE && TRACE_HALF_TILES && (TRACE_HALF_KIND & 1) && TB >= 4 && (TRACE_HALF_L == 0 || TRACE_HALF_L == L_OUT)) {
