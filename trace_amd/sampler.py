@@ -205,7 +205,7 @@ class TraceSampler:
         ws = self._buf("unet_ws", (ws_bytes,), torch.uint8)
         x_in = self._buf("x_in", (R, C_PAD, T), zero=True)
         pred = self._buf("pred", (R, T, 2))
-        x0 = self._buf("x0", (M, T, 2))
+        x0_buf = self._buf("x0", (M, T, 2))
         xa = self._buf("xa", (M, T, 6))
         xb = self._buf("xb", (M, T, 6))
         a_out = self._buf("a_out", (M, T, 2))
@@ -234,6 +234,8 @@ class TraceSampler:
         S = len(steps)
         diffusion = None
         if return_diffusion:
+            # the chain x_T .. x_0 is kept: step k reads diffusion[k] and writes diffusion[k + 1] in place of the
+            # xa / xb ping-pong (no copy per step)
             diffusion = self._buf("diffusion", (S + 1, M, T, 6))
             diffusion[0].copy_(xa)
         # all step noise up front (the reference draws one randn_like per step, trace.py:655; an
@@ -248,9 +250,13 @@ class TraceSampler:
             st_ = self._stream()                 # the capturing stream when under graph capture
             x, x_next = xa, xb
             losses = None
+            # without classifier-free guidance x0 IS the denoiser's prediction (trace_cfg_combine would only copy it)
+            x0 = pred if (not use_cfg and w == 0.0) else x0_buf
             for k, t in enumerate(steps):
                 sc = self._coefs(t)
                 csc = C.byref(sc)
+                if diffusion is not None:
+                    x, x_next = diffusion[k], diffusion[k + 1]
                 # denoiser input: trajectory + bilinear map features, cond and uncond rows stacked
                 if use_cfg:
                     _cabi.check(L.trace_map_query_cfg(ptr(x), ptr(grid), ptr(grid_nc), ptr(rfa), ptr(x_in), M, N,
@@ -261,8 +267,9 @@ class TraceSampler:
                                                   C_PAD, img_w, img_h, dyn, st_), "trace_map_query")
                 _cabi.check(L.trace_unet_forward(self._unet, ptr(x_in), ptr(table), N, t, R, ptr(pred),
                                                  ptr(ws), ws_bytes, save, st_), "trace_unet_forward")
-                _cabi.check(L.trace_cfg_combine(ptr(pred), pred[M:].data_ptr() if use_cfg else None,
-                                                ptr(x), ptr(x0), M, T, w, csc, st_), "trace_cfg_combine")
+                if x0 is not pred:
+                    _cabi.check(L.trace_cfg_combine(ptr(pred), pred[M:].data_ptr() if use_cfg else None,
+                                                    ptr(x), ptr(x0), M, T, w, csc, st_), "trace_cfg_combine")
                 grad = None
                 if guided:
                     if guide_clean:
@@ -303,8 +310,6 @@ class TraceSampler:
                                                     st_), "trace_dyn_rollout")
                     losses = plan_.evaluate(traj, None, st_)
                 x, x_next = x_next, x
-                if diffusion is not None:
-                    diffusion[k + 1].copy_(x)
             return x, losses
 
         if use_graph:
