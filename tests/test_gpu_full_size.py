@@ -382,12 +382,13 @@ def test_every_denoiser_buffer_is_bit_reproducible(full):
     assert float(runs[0][3].view(torch.float32).abs().max()) > 0
 
 
-@pytest.mark.parametrize("rows", [320, 1000, 2560])
+@pytest.mark.parametrize("rows", [20, 320, 340, 1000, 2560])
 def test_small_launch_tiles_give_the_same_bits_as_full_tiles(full, rows):
     """Launches of at most one full tile per CU run on HALF tiles (Bf3Geom: 104 rows per workgroup, three weight
     slices in flight; conv_bf3_kernels.h launch_conv_bf3).  The first `rows` rows of a 10240-row denoiser call (full
     tiles, two row halves on two streams) and a call on those rows alone (half tiles at every level for 320 rows, at
-    some levels for 1000 / 2560) must agree bit for bit: prediction and input gradient.  This holds because every
+    some levels for 1000 / 2560; 20 and 340 leave ragged tiles: 340 = 42.5 half tiles at L = 13) must agree bit for bit:
+    prediction and input gradient.  This holds because every
     floating-point contraction of the epilogues is spelled out (common.h mish_fast_f, conv_epilogue)."""
     from trace_amd import _cabi
     f = full
