@@ -85,7 +85,10 @@ int64_t trace_unet_workspace_bytes(const trace_unet* u, int rows, int save);
  * (rows = 2M) so both passes of tbsim/models/trace.py:572,588 run as one call.
  * Calls of 4096 rows and more launch half of their rows on a second stream owned by `u` (joined back
  * into `stream` before the call returns control of it; not under stream capture): one call at a
- * time per trace_unet. */
+ * time per trace_unet.
+ * A row's prediction (and its input gradient below) does not depend on how many rows the call has: groups of 16
+ * consecutive rows share operand scales, so any call whose rows start at a multiple of 16 reproduces its rows of a
+ * larger call bit for bit, whichever tile shape the launch sizes select (tests/test_gpu_full_size.py). */
 int trace_unet_forward(trace_unet* u, const float* x_in, const float* cond_table,
                        int rows_per_cond, int step, int rows, float* pred, void* workspace,
                        int64_t workspace_bytes, int save, void* stream);

@@ -7,7 +7,9 @@
 // error 5.3e-7, the native fp32 MFMA 5.8e-7; rate 405 vs 154 fp32-equivalent TFLOP/s.
 //
 // Tile: 208 rows x 64 output channels per workgroup, wave w owns channels 16w .. 16w+15 and all 13 row tiles;
-// the fused epilogues (GroupNorm + Mish forward / backward, residuals) are conv_kernels.h's conv_epilogue.
+// launches of at most one such tile per CU take HALF tiles (104 rows, 7 row tiles, the last half phantom: Bf3Geom;
+// same bits).  The fused epilogues (GroupNorm + Mish forward / backward, residuals) are
+// conv_kernels.h's conv_epilogue.
 //
 // A operand: activations stay fp32 in HBM.  A chunk of 32 channels is fetched global -> VGPR
 //            (8 channels x 1 position per thread and pass, dword buffer loads coalesced along the
@@ -19,7 +21,8 @@
 //            16 consecutive 16-byte slots: conflict-free (the [position][channel] image of the first
 //            version spent 62 % of its LDS cycles on bank conflicts, LDS 66 % busy).
 // B operand: weights split and packed on the host in fragment order [col tile][slice][plane][lane],
-//            streamed L2 -> VGPR two slices (one slice = one tap x 32 channels) ahead.
+//            streamed L2 -> VGPR WPF slices (one slice = one tap x 32 channels) ahead: one on full tiles, three on
+//            half tiles (a lone workgroup per CU has no co-resident wave to cover the round trip).
 // rows     : row tile rt = positions PPT rt .. of ALL trajectories of the workgroup (PPT = L / 13), so
 //            one base address serves every tile (+ immediates) and the 16 rows of a read are 16
 //            trajectories x positions at distinct slots (Bf3Geom::lp_pad); the epilogue's ROWMAP = 1
@@ -525,19 +528,13 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(ConvArgs a, ConvArgs 
 #ifndef TRACE_HALF_WPF
 #define TRACE_HALF_WPF 3          // weight slices in flight on half tiles (cfg1: 1 -> 74.6, 2 -> 66.2, 3 -> 65.7, 4 -> 65.8 ms per call)
 #endif
-#ifndef TRACE_HALF_KIND
-#define TRACE_HALF_KIND 7         // diagnostic: bit 0 pair launches, bit 1 stride-2 launches, bit 2 the others
-#endif
-#ifndef TRACE_HALF_L
-#define TRACE_HALF_L 0            // diagnostic: half tiles at this L_OUT only (0 = every length)
-#endif
 #ifndef TRACE_SMALL_WGS
 #define TRACE_SMALL_WGS 256       // full tiles of a launch up to which it runs on half tiles (256 = one workgroup per CU)
 #endif
 constexpr long SMALL_WGS = TRACE_SMALL_WGS;
 template <int L_OUT, int TB, bool MAY_HALVE = true>
 int launch_conv_pair(const ConvArgs& a, const ConvArgs& b, hipStream_t st) {
-  if constexpr (MAY_HALVE && TRACE_HALF_TILES && (TRACE_HALF_KIND & 1) && TB >= 4 && (TRACE_HALF_L == 0 || TRACE_HALF_L == L_OUT)) {
+  if constexpr (MAY_HALVE && TRACE_HALF_TILES && TB >= 4) {
     if ((long)((a.rows + TB - 1) / TB) * ((a.cout + b.cout) / 64) <= SMALL_WGS)
       return launch_conv_pair<L_OUT, TB / 2, false>(a, b, st);
   }
@@ -653,7 +650,7 @@ int conv_scheme(int mode);                                     // unet.hip (trac
 // stride-2 convs (32-channel chunks: a chunk already stages 2 L_OUT positions per trajectory)
 template <int L_OUT, int TAPS, int PADL, int TB, bool MAY_HALVE = true>
 int launch_conv_bf3_s2(const ConvArgs& a, hipStream_t st) {
-  if constexpr (MAY_HALVE && TRACE_HALF_TILES && (TRACE_HALF_KIND & 2) && TB >= 4 && (TRACE_HALF_L == 0 || TRACE_HALF_L == L_OUT)) {
+  if constexpr (MAY_HALVE && TRACE_HALF_TILES && TB >= 4) {
     if ((long)((a.rows + TB - 1) / TB) * (a.cout / 64) <= SMALL_WGS)
       return launch_conv_bf3_s2<L_OUT, TAPS, PADL, TB / 2, false>(a, st);
   }
@@ -667,7 +664,7 @@ template <int L_OUT, int UP, int TAPS, int PADL, int TB, bool MAY_HALVE = true>
 int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
   constexpr int MW = TRACE_BF3_WGS * TRACE_BF3_NW / 4;
   const long wgs = (long)((a.rows + TB - 1) / TB) * (a.cout / 64);
-  if constexpr (MAY_HALVE && TRACE_HALF_TILES && (TRACE_HALF_KIND & 4) && TB >= 4 && (TRACE_HALF_L == 0 || TRACE_HALF_L == L_OUT)) {
+  if constexpr (MAY_HALVE && TRACE_HALF_TILES && TB >= 4) {
     if (wgs <= SMALL_WGS) return launch_conv_bf3<L_OUT, UP, TAPS, PADL, TB / 2, false>(a, st);
   }
   if (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax)) {          // every operand has its scale: the fp16 pipe
