@@ -501,6 +501,9 @@ def test_free_running_sample_vs_reference_golden(name):
                     noise_init=c["noise_init"], noise_steps=c["noise_steps"])
     pos = out["predictions"]["positions"].cpu()
     assert bool(torch.isfinite(pos).all())
+    # the returned reverse chain (written in place by the step kernels, sampler.py): its last entry IS the sample
+    ds = out["predictions"]["diffusion_steps"].cpu()
+    assert torch.equal(ds[:, :, :, -1, :2], pos)
     if name in UNSTABLE:
         # noisy guidance at the eval-config weights: the free-running chain is an unstable feedback loop in
         # the reference itself; its strict comparison is the teacher-forced test above
@@ -510,6 +513,12 @@ def test_free_running_sample_vs_reference_golden(name):
     print("free-running ADE vs golden (%s): %.3g m" % (name, ade))
     if not chaotic:
         assert ade < 1e-3, ade
+        if "diffusion_steps" in gold:         # every entry of the chain, not only the last
+            gd = torch.tensor(gold["diffusion_steps"])
+            assert gd.shape == ds.shape, (gd.shape, ds.shape)
+            dd = float(torch.norm(ds[..., :2] - gd[..., :2], dim=-1).mean())
+            print("free-running chain (all %d entries) vs golden (%s): %.3g m" % (ds.shape[3], name, dd))
+            assert dd < 1e-3, dd
     else:
         # observed 0.12 m (clean_all) / 0.26 m (noisy_all); two reference runs 1 ulp apart end 0.28 m apart
         print("free-running ADE vs golden with map_collision guidance: %.4f m" % ade)
