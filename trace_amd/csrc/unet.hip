@@ -202,6 +202,99 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
   if (dy_amax) record_amax(dy_amax, row & ~15, mo);
 }
 
+// The same backward with one WORKGROUP per row (round 3): the eight groups of a row go to the eight half-waves, a
+// lane takes 16-byte cells of its group's contiguous cg L floats (104 cells at C = 64, L = 52: at most four per
+// lane), the two group sums are reduced over the 32 lanes on DPP modifiers + v_readlane (group_sum, conv_kernels.h)
+// instead of twelve ds_bpermute round trips, and the head's gradient arrives as two 16-byte loads per cell.
+// Requires L % 4 == 0 and (C / 8) L / 4 <= 128.  One wave per (row, group) with scalar loads (the kernel above) ran
+// at 2.7 TB/s of its 272 MB.
+template <int L, int CG>
+__global__ __launch_bounds__(256) void gn_mish_bwd_row_kernel(const float* __restrict__ da, int da_tstride, int da_coff,
+                                                              const float* __restrict__ y,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              float* __restrict__ dy, int rows,
+                                                              const float* __restrict__ head_g,
+                                                              const float* __restrict__ head_w,
+                                                              float* __restrict__ gscale,
+                                                              unsigned* __restrict__ dy_amax) {
+#pragma clang fp contract(off)
+  static_assert(L % 4 == 0 && CG * L / 4 <= 128, "cells of 4 positions, at most four per lane");
+  constexpr int C = 8 * CG, LQ = L / 4, NG4 = CG * LQ, K = (NG4 + 31) / 32;
+  const int row = blockIdx.x;
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63, l32 = threadIdx.x & 31;
+  const int g = threadIdx.x >> 5;
+  const float mean = stats[((size_t)row * 8 + g) * 2];
+  const float rstd = stats[((size_t)row * 8 + g) * 2 + 1];
+  const f32x4* yb = reinterpret_cast<const f32x4*>(y + ((size_t)row * C + g * CG) * L);
+  const f32x4* db = reinterpret_cast<const f32x4*>(da + (size_t)row * da_tstride + (size_t)(da_coff + g * CG) * L);
+  f32x4* ob = reinterpret_cast<f32x4*>(dy + ((size_t)row * C + g * CG) * L);
+  float hs = 1.f;
+  if (head_g && gscale) {             // per-trajectory power of two of the incoming gradient (see the kernel above)
+    float m = 0.f;
+    for (int e = lane; e < 2 * L; e += 64) m = fmaxf(m, fabsf(head_g[(size_t)row * L * 2 + e]));
+    m = wave_max_nonneg(m);
+    const int ef = (int)(__builtin_bit_cast(unsigned, m) >> 23);
+    if (ef >= 1 && ef <= 253) {
+      hs = __builtin_bit_cast(float, (unsigned)(254 - ef) << 23);
+      if (threadIdx.x == 0) gscale[row] = __builtin_bit_cast(float, (unsigned)ef << 23);
+    } else if (threadIdx.x == 0) {
+      gscale[row] = 1.f;
+    }
+  }
+  float gg[K][4], xh[K][4];
+  float s[2] = {0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int f = l32 + 32 * k;
+    const bool live = f < NG4;
+    const int fc = live ? f : 0;
+    const int c = fc / LQ, t4 = fc - c * LQ, ch = g * CG + c;
+    const f32x4 yv = yb[fc];
+    const float ga = gamma[ch], be = beta[ch];
+    f32x4 up;
+    if (head_g) {
+      const f32x4* gp = reinterpret_cast<const f32x4*>(head_g + ((size_t)row * L + 4 * t4) * 2);
+      const f32x4 p0 = gp[0], p1 = gp[1];
+      const float w0 = head_w[ch], w1 = head_w[C + ch];
+      up[0] = w0 * (p0[0] * hs) + w1 * (p0[1] * hs);
+      up[1] = w0 * (p0[2] * hs) + w1 * (p0[3] * hs);
+      up[2] = w0 * (p1[0] * hs) + w1 * (p1[1] * hs);
+      up[3] = w0 * (p1[2] * hs) + w1 * (p1[3] * hs);
+    } else {
+      up = db[fc];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float x = (yv[i] - mean) * rstd;
+      const float z = __builtin_fmaf(x, ga, be);
+      const float gz = live ? up[i] * mish_grad_fast_f(z) * ga : 0.f;
+      gg[k][i] = gz;
+      xh[k][i] = x;
+      s[0] += gz;
+      s[1] = __builtin_fmaf(gz, x, s[1]);
+    }
+  }
+  group_sum<2>(s, 32);
+  const float inv_n = 1.f / (float)(CG * L);
+  const float m1 = s[0] * inv_n, m2 = s[1] * inv_n;
+  float mo = 0.f;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int f = l32 + 32 * k;
+    if (f < NG4) {
+      f32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = rstd * (gg[k][i] - m1 - xh[k][i] * m2);
+      ob[f] = o;
+      mo = amax4(mo, o);
+    }
+  }
+  if (dy_amax) record_amax(dy_amax, row & ~15, mo);
+}
+
 // final 1x1 conv (C -> 2) + transpose:  pred[row][t][o] = b[o] + sum_c W[o][c] f[row][c][t]
 // One thread = 4 consecutive positions (16-byte loads / stores); requires L % 4 == 0.
 __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ f,
@@ -241,16 +334,21 @@ __global__ __launch_bounds__(256) void first_dgrad_kernel(const float* __restric
                                                           const float* __restrict__ rsel,
                                                           float* __restrict__ gx, int C, int L, int rows,
                                                           const float* __restrict__ gscale) {
+  // 64 (row, quad) outputs per workgroup; wave w sums channels [w C/4, (w+1) C/4) (lanes run along the quads, so the
+  // loads stay coalesced), the four partial sums meet in LDS and wave 0 adds them in wave order: four times the
+  // waves in flight of the one-thread-per-output form, which was bound by its 64 serial channel steps
+  __shared__ float part[3][64][8];
   const int nq = L >> 2;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= rows * nq) return;
-  const int row = idx / nq, q = idx - row * nq, t0 = q * 4;
-  const float gs = gscale ? gscale[row] : 1.f;         // undo the head's per-trajectory power of two
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int idx = blockIdx.x * 64 + lane;
+  const bool live = idx < rows * nq;
+  const int row = live ? idx / nq : 0, q = live ? idx - row * nq : 0, t0 = q * 4;
   const float* yb = dy1 + (size_t)row * C * L + t0;
   const float* ob = dout + (size_t)row * C * L + t0;
   float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  for (int co = 0; co < C; ++co) {
+  const int cper = C >> 2;
+  for (int co = w * cper; co < (w + 1) * cper; ++co) {
     const float* yr = yb + (size_t)co * L;
     const f32x4 lo = q > 0 ? *reinterpret_cast<const f32x4*>(yr - 4) : zero;
     const f32x4 mi = *reinterpret_cast<const f32x4*>(yr);
@@ -270,6 +368,18 @@ __global__ __launch_bounds__(256) void first_dgrad_kernel(const float* __restric
       a1[i] = fmaf(o[i], r1, a1[i]);
     }
   }
+  if (w > 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { part[w - 1][lane][i] = a0[i]; part[w - 1][lane][4 + i] = a1[i]; }
+  }
+  __syncthreads();
+  if (w != 0 || !live) return;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a0[i] += part[k][lane][i]; a1[i] += part[k][lane][4 + i]; }
+  }
+  const float gs = gscale ? gscale[row] : 1.f;         // undo the head's per-trajectory power of two
   f32x4* out = reinterpret_cast<f32x4*>(gx + ((size_t)row * L + t0) * 2);
   out[0] = f32x4{a0[0] * gs, a1[0] * gs, a0[1] * gs, a1[1] * gs};
   out[1] = f32x4{a0[2] * gs, a1[2] * gs, a0[3] * gs, a1[3] * gs};
@@ -969,6 +1079,13 @@ int run_gn_bwd(const View& da, const float* y, const float* stats, const float* 
                const float* head_g = nullptr, const float* head_w = nullptr, float* gscale = nullptr,
                unsigned* dy_amax = nullptr) {
   int cg = C / 8;
+  const bool aligned16 = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(da.p) |
+                           reinterpret_cast<uintptr_t>(head_g)) & 15) == 0 && da.tstride() % 4 == 0 && (da.coff * L) % 4 == 0;
+  if (C == 64 && L == 52 && aligned16) {        // the head's GroupNorm: one workgroup per row
+    hipLaunchKernelGGL((gn_mish_bwd_row_kernel<52, 8>), dim3(rows), dim3(256), 0, st, da.p, da.tstride(), da.coff, y,
+                       stats, gamma, beta, dy, rows, head_g, head_w, gscale, dy_amax);
+    return launch_status("gn_mish_bwd_row_kernel");
+  }
   dim3 grid((rows * 8 + 3) / 4);
 #define GNB(LL)                                                                              \
   hipLaunchKernelGGL(gn_mish_bwd_kernel<LL>, grid, dim3(256), 0, st, da.p, da.tstride(), da.coff, \
@@ -1317,7 +1434,8 @@ extern "C" int trace_unet_backward_input(trace_unet* u, const float* grad_pred_a
     RUN(run_conv(K_CONV5, b.L, a, st));
     TRACE_REQUIRE(H % 4 == 0, "first_dgrad: horizon %d not a multiple of 4", H);
     int n = rows * (H / 4);
-    hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 255) / 256), dim3(256), 0, st, t2.p, buf(iG0),
+    TRACE_REQUIRE(d0 % 4 == 0, "first_dgrad: %d channels not a multiple of 4", d0);
+    hipLaunchKernelGGL(first_dgrad_kernel, dim3((n + 63) / 64), dim3(256), 0, st, t2.p, buf(iG0),
                        u->first_wsel, u->first_rsel, grad_x, d0, H, rows, gscale);
     RUN(launch_status("first_dgrad_kernel"));
   }
