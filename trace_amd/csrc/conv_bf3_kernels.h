@@ -668,10 +668,13 @@ int launch_conv_bf3(const ConvArgs& a, hipStream_t st) {
     if (wgs <= SMALL_WGS) return launch_conv_bf3<L_OUT, UP, TAPS, PADL, TB / 2, false>(a, st);
   }
   if (a.wh && a.in_amax && (a.cin2 == 0 || a.in2_amax)) {          // every operand has its scale: the fp16 pipe
+#ifndef TRACE_F16_CH1
+#define TRACE_F16_CH1 64          // ... and of the 1x1 launches (32: 10.09 ms per pass, 64: 10.02; same bits)
+#endif
 #ifndef TRACE_F16_CH
 #define TRACE_F16_CH 64           // channels per chunk of the fp16 launches with more than one tap (32 / 64; build switch)
 #endif
-    if constexpr (TAPS > 1 && TRACE_F16_CH == 64) {
+    if constexpr ((TAPS > 1 || TRACE_F16_CH1 == 64) && TRACE_F16_CH == 64) {
       if (a.cin % 64 == 0 && a.cin2 % 64 == 0)
         return launch_conv_bf3_impl<L_OUT, UP, TAPS, PADL, TB, 1, TRACE_BF3_NW, MW, 64, 1, (MAY_HALVE ? TRACE_BF3_WPF : TRACE_HALF_WPF)>(a, st);
     }
