@@ -185,6 +185,22 @@ def _fwd_vjp_errors(cfg, batch, sd, x, t, lib, cabi):
     return res
 
 
+def test_denoiser_of_a_wider_unet(env):
+    """base_dim = 64 (UNet widths 128 / 256 / 512; a 128-channel head: GroupNorm groups of 16 x 52 = 832 elements)
+    against the CPU oracle, forward and input-VJP, both operand schemes.  Round 3 found the head's GroupNorm backward
+    silently dropping everything past 448 elements of a group on this width (input gradient off by its own size);
+    the default width never exercised it."""
+    cfg = ModelConfig(base_dim=64)
+    assert cfg.unet_dims[1:] == [128, 256, 512]
+    sd = random_state_dict(cfg, 3)
+    batch = syn.make_batch(cfg, env["aps"], seed=1, extent=(0.9, 0.7, 1.75), dense=True)
+    x = torch.randn(15, cfg.horizon, 6, generator=torch.Generator().manual_seed(5))
+    res = _fwd_vjp_errors(cfg, batch, sd, x, 37, env["lib"], env["cabi"])
+    for mode, (e_x0, e_g) in res.items():
+        assert float(e_x0.max()) < 1e-4, (mode, float(e_x0.max()))
+        assert float(e_g.max()) < 2e-4, (mode, float(e_g.max()))
+
+
 def test_fp16_pair_convs_on_heavy_tailed_weights(env):
     """Weights whose magnitudes spread over many octaves inside one layer, as a trained checkpoint's can (the weight
     scale 2^wexp is per LAYER, unet.hip:pack_conv, so a layer's small weights sit far below the scaled maximum of 2^14
