@@ -185,13 +185,15 @@ def _fwd_vjp_errors(cfg, batch, sd, x, t, lib, cabi):
     return res
 
 
-def test_denoiser_of_a_wider_unet(env):
-    """base_dim = 64 (UNet widths 128 / 256 / 512; a 128-channel head: GroupNorm groups of 16 x 52 = 832 elements)
-    against the CPU oracle, forward and input-VJP, both operand schemes.  Round 3 found the head's GroupNorm backward
-    silently dropping everything past 448 elements of a group on this width (input gradient off by its own size);
-    the default width never exercised it."""
-    cfg = ModelConfig(base_dim=64)
-    assert cfg.unet_dims[1:] == [128, 256, 512]
+@pytest.mark.parametrize("widths", [(64, (2, 4, 8)), (32, (8, 8, 8))])
+def test_denoiser_of_a_wider_unet(env, widths):
+    """UNet widths 128 / 256 / 512 (base_dim = 64) and 256 / 256 / 256: a 128- / 256-channel head, GroupNorm groups of
+    16 x 52 = 832 / 32 x 52 = 1664 elements, against the CPU oracle, forward and input-VJP, both operand schemes.
+    Round 3 found the head's GroupNorm backward silently dropping everything past 448 elements of a group on such
+    widths (input gradient off by its own size); the default width never exercised it.  (Widths above 512 are
+    refused by trace_unet_create.)"""
+    cfg = ModelConfig(base_dim=widths[0], dim_mults=widths[1])
+    assert cfg.unet_dims[1] in (128, 256)
     sd = random_state_dict(cfg, 3)
     batch = syn.make_batch(cfg, env["aps"], seed=1, extent=(0.9, 0.7, 1.75), dense=True)
     x = torch.randn(15, cfg.horizon, 6, generator=torch.Generator().manual_seed(5))

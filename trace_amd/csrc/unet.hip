@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_kernel(const float* __restric
 // lane takes 16-byte cells of its group's contiguous cg L floats (104 cells at C = 64, L = 52: at most four per
 // lane), the two group sums are reduced over the 32 lanes on DPP modifiers + v_readlane (group_sum, conv_kernels.h)
 // instead of twelve ds_bpermute round trips, and the head's gradient arrives as two 16-byte loads per cell.
-// Requires L % 4 == 0 and (C / 8) L / 4 <= 256 (C = 64 / 128 at L = 52).  One wave per (row, group) with scalar loads (the kernel above) ran
+// Requires L % 4 == 0 and (C / 8) L / 4 <= 512 (C = 64 / 128 / 256 at L = 52).  One wave per (row, group) with scalar loads (the kernel above) ran
 // at 2.7 TB/s of its 272 MB.
 template <int L, int CG>
 __global__ __launch_bounds__(256) void gn_mish_bwd_row_kernel(const float* __restrict__ da, int da_tstride, int da_coff,
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void gn_mish_bwd_row_kernel(const float* __res
                                                               float* __restrict__ gscale,
                                                               unsigned* __restrict__ dy_amax) {
 #pragma clang fp contract(off)
-  static_assert(L % 4 == 0 && CG * L / 4 <= 256, "cells of 4 positions, at most eight per lane");
+  static_assert(L % 4 == 0 && CG * L / 4 <= 512, "cells of 4 positions, at most sixteen per lane");
   constexpr int C = 8 * CG, LQ = L / 4, NG4 = CG * LQ, K = (NG4 + 31) / 32;
   const int row = blockIdx.x;
   if (row >= rows) return;
@@ -1081,8 +1081,11 @@ int run_gn_bwd(const View& da, const float* y, const float* stats, const float* 
   int cg = C / 8;
   const bool aligned16 = ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(da.p) |
                            reinterpret_cast<uintptr_t>(head_g)) & 15) == 0 && da.tstride() % 4 == 0 && (da.coff * L) % 4 == 0;
-  if ((C == 64 || C == 128) && L == 52 && aligned16) {        // the head's GroupNorm: one workgroup per row
-    if (C == 64)
+  if ((C == 64 || C == 128 || C == 256) && L == 52 && aligned16) {        // the head's GroupNorm: one workgroup per row
+    if (C == 256)
+      hipLaunchKernelGGL((gn_mish_bwd_row_kernel<52, 32>), dim3(rows), dim3(256), 0, st, da.p, da.tstride(), da.coff, y,
+                         stats, gamma, beta, dy, rows, head_g, head_w, gscale, dy_amax);
+    else if (C == 64)
       hipLaunchKernelGGL((gn_mish_bwd_row_kernel<52, 8>), dim3(rows), dim3(256), 0, st, da.p, da.tstride(), da.coff, y,
                          stats, gamma, beta, dy, rows, head_g, head_w, gscale, dy_amax);
     else
