@@ -117,8 +117,8 @@ double trace_profile_pipe_seconds(void);
 
 /* Kernel choice for the full-chip multi-tap convolutions of the denoiser: 0 = conv_bf3_kernel (two workgroups
  * per CU, the default), 1 = conv_ws_kernel (persistent, wave-specialised: csrc/conv_ws_kernels.h), -1 = leave
- * as is.  Both give the same bits; the switch exists for A/B measurements and tests.  Initial value: environment
- * variable TRACE_CONV_WS (default 0).  Returns the previous value.  No counterpart in the reference. */
+ * as is.  Both give the same bits; the switch exists for A/B measurements and tests.  Initial value 0 (the library
+ * reads no environment variable).  Returns the previous value.  No counterpart in the reference. */
 int trace_conv_ws_mode(int mode);
 
 /* Operand scheme of the denoiser's implicit-GEMM convolutions (fp32 results either way): 1 (default) = every fp32
@@ -126,8 +126,8 @@ int trace_conv_ws_mode(int mode);
  * range by exact powers of two (weights: per layer on the host; activations: per 16 trajectories from the largest
  * |value| the producing kernel recorded) -- used by every launch whose inputs all carry such a scale, the others
  * stay on 0; 0 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per product everywhere; -1 = leave as is.  The
- * wave-specialised kernel (trace_conv_ws_mode) only runs under scheme 0.  Initial value: environment variable
- * TRACE_CONV_SCHEME ("bf16x3" / "fp16x2", default fp16x2).  Returns the previous value.  No counterpart in the
+ * wave-specialised kernel (trace_conv_ws_mode) only runs under scheme 0.  Initial value 1 (the library reads no environment
+ * variable).  Returns the previous value.  No counterpart in the
  * reference (tbsim/models/temporal.py runs torch fp32 convolutions). */
 int trace_conv_scheme(int mode);
 
